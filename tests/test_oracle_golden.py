@@ -1,0 +1,167 @@
+"""The CPU oracle against the fixtures produced by the reference itself (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gptq_oracle as oracle
+from tests.conftest import load_golden, t
+
+
+@pytest.mark.parametrize("tag,dtype", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_add_batch_matches_reference(tag, dtype):
+    g = load_golden(f"f1_xtx_{tag}")
+    hook = oracle.OracleHessian()
+    for i in range(4):
+        x = t(g[f"x{i}"], dtype) if dtype == torch.bfloat16 else t(g[f"x{i}"])
+        hook.add_batch(x)
+        assert hook.n_samples == int(g[f"n{i}"])  # a 2-D batch counts as one sample
+        assert torch.equal(hook.hessian, t(g[f"h{i}"]))  # same torch.addmm, same bits
+
+
+def test_xtx_exact_is_within_fp32_accumulation_error_of_reference():
+    g = load_golden("f1_xtx_f16")
+    h = torch.zeros(256, 256)
+    for i in range(4):
+        x = t(g[f"x{i}"])
+        oracle.xtx_accumulate_exact(h, x.reshape(-1, 256).contiguous())
+        ref = t(g[f"h{i}"])
+        assert torch.equal(h, h.t())
+        assert (h - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
+@pytest.mark.parametrize("name", ["act", "noact", "dead", "lowrank"])
+def test_invert_matches_reference(name):
+    g = load_golden(f"f2_invert_{name}")
+    hook = oracle.OracleHessian()
+    hook.hessian = t(g["h_raw"]).clone()
+    hook.n_samples = int(g["n_samples"])
+    u = hook.invert(damp_ratio=float(g["damp_ratio"]), act_order=bool(g["act_order"]))
+    assert hook.tries == int(g["tries"])
+    if bool(g["act_order"]):
+        assert torch.equal(hook.perm, t(g["perm"]))
+        assert torch.equal(hook.perm_inv, t(g["perm_inv"]))
+    assert torch.equal(hook.hessian, t(g["hessian_after"]))
+    assert torch.equal(u, t(g["hessian_inv"]))
+    # and the fp64 factor agrees with the reference's fp32 one to fp32 accuracy
+    u64 = oracle.upper_inverse_factor_f64(hook.hessian)
+    rel = (u.double() - u64).norm() / u64.norm()
+    assert rel < 1e-4, rel
+
+
+def test_find_params_quantize_dequantize_match_reference():
+    g = load_golden("f3_find_params")
+    w = t(g["w"])
+    for bits in (2, 3, 4, 8):
+        for sym in (False, True):
+            tag = f"b{bits}_{'sym' if sym else 'asym'}"
+            s, z, mq = oracle.find_params(w, bits, sym)
+            assert mq == float(g[f"maxq_{tag}"])
+            assert torch.equal(s, t(g[f"scale_{tag}"])), tag
+            assert torch.equal(z, t(g[f"qzero_{tag}"])), tag
+            q = oracle.quantize(w, s, z, mq)
+            assert torch.equal(q, t(g[f"q_{tag}"])), tag
+            assert torch.equal(oracle.dequantize(q, s, z), t(g[f"dq_{tag}"])), tag
+
+
+def _hook_from(g):
+    hook = oracle.OracleHessian()
+    hook.hessian = t(g["h_raw"]).clone()
+    hook.n_samples = int(g["n_samples"])
+    hook.invert(damp_ratio=1e-2, act_order=bool(g["act_order"]))
+    assert torch.equal(hook.hessian_inv, t(g["hessian_inv"]))
+    return hook
+
+
+CASES = ["64x256_b4", "128x384_b3", "64x256_b4_noact"]
+
+
+def _check_meta(res, g, exact_metrics_rtol=1e-5):
+    meta = res["quant_meta"]
+    assert torch.equal(meta["qweight"], t(g["qweight"]))
+    assert torch.equal(meta["scale"], t(g["scale"]))
+    assert torch.equal(meta["qzero"], t(g["qzero"]))
+    assert torch.equal(meta["perm_inv"], t(g["perm_inv"]))
+    assert torch.equal(meta["group_sizes"], t(g["meta_group_sizes"]))
+    assert torch.equal(meta["group_bit_widths"], t(g["meta_group_bit_widths"]))
+    m = res["metrics"]
+    got = np.array([m["gptq_error"], m["gptq_norm"], m["l2.0_error"], m["l2.0_norm"]])
+    np.testing.assert_allclose(got, g["metrics"], rtol=exact_metrics_rtol)
+    w = oracle.construct_weight(meta, torch.float16)
+    assert torch.equal(w, t(g["recon_weight"]))
+    y = torch.nn.functional.linear(t(g["lin_x"]), w)
+    assert torch.equal(y, t(g["lin_y"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gptq_quant_python_semantics_matches_reference(case):
+    g = load_golden(f"f4_pysem_{case}")
+    hook = _hook_from(g)
+    res = oracle.gptq_quant(t(g["w"]), hook, t(g["group_sizes"]), t(g["group_bit_widths"]),
+                            use_kernel_semantics=False, block_sizes=t(g["group_sizes"]))
+    _check_meta(res, g)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gptq_quant_kernel_semantics_matches_reference_glue(case):
+    g = load_golden(f"f5_kernelsem_{case}")
+    hook = _hook_from(g)
+    res = oracle.gptq_quant(t(g["w"]), hook, t(g["group_sizes"]), t(g["group_bit_widths"]),
+                            use_kernel_semantics=True)
+    _check_meta(res, g)
+    # identities the reference implies for the native path:
+    #  quant == reconstructed weight in permuted order, bit for bit (fp16 dequant in the loop)
+    wq = oracle.construct_weight(res["quant_meta"], torch.float16, unpermute=False)
+    assert torch.equal(res["debug"]["quant"], wq.float())
+    #  first group's grid is the Python path's (both read the unmodified weights there)
+    gp = load_golden(f"f4_pysem_{case}")
+    assert np.array_equal(g["scale"][:, 0], gp["scale"][:, 0])
+    assert np.array_equal(g["qzero"][:, 0], gp["qzero"][:, 0])
+    assert np.array_equal(g["qweight"][:, :1], gp["qweight"][:, :1])
+
+
+def test_rtn_matches_reference():
+    g = load_golden("f7_rtn_64x256_b4")
+    res = oracle.gptq_quant(t(g["w"]), None, t(g["group_sizes"]), t(g["group_bit_widths"]))
+    meta = res["quant_meta"]
+    assert torch.equal(meta["qweight"], t(g["qweight"]))
+    assert torch.equal(meta["scale"], t(g["scale"]))
+    assert torch.equal(meta["qzero"], t(g["qzero"]))
+    assert torch.equal(meta["perm_inv"], t(g["perm_inv"]))
+    assert torch.equal(oracle.construct_weight(meta), t(g["recon_weight"]))
+
+
+def test_fp16_emulation_matches_numpy():
+    lib = oracle._lib()
+    rng = np.random.default_rng(0)
+    f = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s
+                        for s in (1e-8, 1e-5, 1e-3, 1.0, 100.0, 7e4)])
+    f = np.concatenate([f, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, 5.96e-8, 2.98e-8,
+                                     2.9802322e-8, 6.1035156e-05, 6.0975552e-05], np.float32)])
+    got = np.array([lib.gqref_f2h(float(x)) for x in f], dtype=np.uint16)
+    with np.errstate(over="ignore"):
+        want = f.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, want)
+    back = np.array([lib.gqref_h2f(int(h)) for h in range(0, 0x7c01)], dtype=np.float32)
+    assert np.array_equal(back, np.arange(0, 0x7c01, dtype=np.uint16).view(np.float16).astype(np.float32))
+    a = rng.integers(0, 0x7c00, 3000).astype(np.uint16)
+    b = rng.integers(0, 0x7c00, 3000).astype(np.uint16) | np.uint16(0x8000) * rng.integers(0, 2, 3000).astype(np.uint16)
+    af, bf = a.view(np.float16).astype(np.float64), b.view(np.float16).astype(np.float64)
+    with np.errstate(over="ignore"):
+        want_sub = (af - bf).astype(np.float16).view(np.uint16)
+        want_mul = (af * bf).astype(np.float16).view(np.uint16)
+    got_sub = np.array([lib.gqref_hsub(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint16)
+    got_mul = np.array([lib.gqref_hmul(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint16)
+    assert np.array_equal(got_sub, want_sub)
+    assert np.array_equal(got_mul, want_mul)
+
+
+@pytest.mark.parametrize("bits,n", [(4, 256), (4, 24), (3, 128), (3, 40), (2, 64), (8, 16)])
+def test_pack_roundtrip(bits, n):
+    gen = torch.Generator().manual_seed(bits * 100 + n)
+    v = torch.randint(0, 1 << bits, (5, n), generator=gen, dtype=torch.uint8)
+    p = oracle.pack_rows(v, bits)
+    assert p.shape == (5, (n * bits + 31) // 32)
+    assert torch.equal(oracle.unpack_rows(p, bits, n), v)
+    if bits == 4:
+        w0 = int(p[0, 0]) & 0xFFFFFFFF
+        assert [(w0 >> (4 * i)) & 15 for i in range(8)] == v[0, :8].tolist()
