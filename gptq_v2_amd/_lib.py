@@ -1,0 +1,74 @@
+"""ctypes binding of libgptq_amd.so (the C ABI declared in include/gptq_amd.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent the import of
+any op fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgptq_amd.so")
+
+# name -> (restype, argtypes); must list every function include/gptq_amd.h declares
+SIGNATURES = {
+    "gq_last_error": (c_char_p, []),
+    "gq_version": (c_int, []),
+    "gq_xtx_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gq_hessian_invert_workspace": (c_size_t, [c_int64]),
+    "gq_hessian_invert": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
+                                  c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "gq_find_params": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p]),
+    "gq_quantize_range": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "gq_quantize_layer_workspace": (c_size_t, [c_int64, c_int64]),
+    "gq_quantize_layer": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64,
+                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), c_int, c_int,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "gq_quantize_rtn": (c_int, [c_void_p, c_int, c_int64, c_int64, ctypes.POINTER(ctypes.c_int32),
+                                ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gq_quant_metrics": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                 c_void_p]),
+    "gq_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p,
+                              c_int, c_void_p, c_void_p]),
+    "gq_pack_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "gq_unpack_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "gq_permute_columns": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gq_w4a16_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                              c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class GqError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is required (build it with "
+                f"`python -m gptq_v2_amd.build`); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gq_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise GqError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,316 @@
+// HessianHook.invert on the device (reference: gptq_py.py:38-66).
+//
+//   H *= 2/n;  dead diagonal -> 1;  perm = argsort(diag, descending);  H = H[perm][:, perm];
+//   damp = ratio * mean(diag);  repeat { diag += damp;  U = chol_upper(inverse(H)) } until it works.
+//
+// The reference obtains U through three LAPACK calls (potrf, potri, potrf: 4C^3/3 flops).  Here
+// U comes from ONE factorisation and ONE triangular inversion (2C^3/3 flops) of the index-
+// reversed matrix:  with J the exchange matrix,  J H J = L L^T  =>  H = (J L J)(J L J)^T  with
+// J L J upper triangular, so  H^-1 = U^T U  for  U = (J L J)^-1 = J L^-1 J,  which is upper
+// triangular with a positive diagonal, i.e. exactly the Cholesky factor the reference computes
+// (the factor is unique).  L and L^-1 are produced together by a recursion on 2x2 block splits
+//     [A 0; B D]:   (L11, L11^-1) = rec(A);   L21 = B L11^-T;   D -= L21 L21^T;
+//                   (L22, L22^-1) = rec(D);   (L^-1)21 = -L22^-1 (L21 L11^-1)
+// whose products run on the fp32 MFMA GEMM (sgemm.hip) and whose 128x128 leaves are factored and
+// inverted inside one workgroup in LDS.
+#include <vector>
+
+#include "sgemm.h"
+
+namespace {
+
+constexpr int NB = 128;  // leaf size == GEMM tile edge (the k-range trimming relies on it)
+
+// ---- element-wise preparation ------------------------------------------------------------
+
+__global__ void scale_kernel(float *__restrict__ h, int64_t c, float s, float *__restrict__ diag)
+{
+    const int64_t total = c * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = h[i] * s;
+        const int64_t r = i / c, col = i - r * c;
+        if (r == col) {
+            if (v == 0.0f) v = 1.0f;   // dead input feature (gptq_py.py:43-44)
+            diag[r] = v;
+        }
+        h[i] = v;
+    }
+}
+
+// damp = ratio * mean(diag); one workgroup, double accumulation
+__global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float ratio, float *__restrict__ damp_out)
+{
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < c; i += 256) s += (double)diag[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *damp_out = ratio * (float)(part[0] / (double)c);
+}
+
+// Stable descending argsort by counting: rank(i) = #{j : d[j] > d[i] or (d[j] == d[i] and j < i)}.
+__global__ void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ perm,
+                                 int32_t *__restrict__ perm_inv)
+{
+    __shared__ float chunk[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float di = i < c ? diag[i] : 0.0f;
+    int rank = 0;
+    for (int base = 0; base < c; base += 1024) {
+        for (int t = threadIdx.x; t < 1024; t += blockDim.x) chunk[t] = base + t < c ? diag[base + t] : 0.0f;
+        __syncthreads();
+        const int lim = min(1024, c - base);
+        for (int t = 0; t < lim; ++t) {
+            const float dj = chunk[t];
+            rank += (dj > di) || (dj == di && base + t < i);
+        }
+        __syncthreads();
+    }
+    if (i < c) {
+        perm[rank] = i;
+        perm_inv[i] = rank;
+    }
+}
+
+// out[i][j] = h[perm[i]][perm[j]]
+__global__ void gather_kernel(const float *__restrict__ h, const int32_t *__restrict__ perm, int64_t c,
+                              float *__restrict__ out)
+{
+    const int64_t total = c * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c, col = i - r * c;
+        out[i] = h[(int64_t)perm[r] * c + perm[col]];
+    }
+}
+
+// h[i][i] += damp, and the index-reversed, identity-padded work matrix  w[i][j] = h[c-1-i][c-1-j]
+__global__ void damp_flip_kernel(float *__restrict__ h, int64_t c, int64_t cp, const float *__restrict__ damp,
+                                 float *__restrict__ w)
+{
+    const float d = *damp;
+    const int64_t total = cp * cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cp, col = i - r * cp;
+        float v;
+        if (r < c && col < c) {
+            const int64_t sr = c - 1 - r, sc = c - 1 - col;
+            v = h[sr * c + sc];
+            if (sr == sc) {
+                v += d;
+                h[sr * c + sc] = v;
+            }
+        } else {
+            v = r == col ? 1.0f : 0.0f;
+        }
+        w[i] = v;
+    }
+}
+
+// u[i][j] = linv[c-1-i][c-1-j] on and above the diagonal, 0 below
+__global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64_t cp, float *__restrict__ u)
+{
+    const int64_t total = c * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c, col = i - r * c;
+        u[i] = col >= r ? linv[(c - 1 - r) * cp + (c - 1 - col)] : 0.0f;
+    }
+}
+
+// ---- 128x128 leaf: L = chol(A) and L^-1, one workgroup, everything in LDS ------------------
+// Reads the lower triangle of w[o:o+128, o:o+128]; writes the full 128x128 block of linv (zeros
+// above the diagonal).  A pivot that is not a positive finite number raises *status.
+__global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, float *__restrict__ linv, int64_t ld,
+                                                   int64_t o, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *a = reinterpret_cast<float *>(smem_raw);   // [128][129]  A, then L
+    float *x = a + NB * 129;                          // [128][129]  L^-1, x[k][c]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        a[r * 129 + c] = c <= r ? w[(o + r) * ld + o + c] : 0.0f;
+    }
+    __syncthreads();
+
+    // right-looking Cholesky; thread t owns row (t & 127) and the columns of parity (t >> 7)
+    const int row = tid & 127, par = tid >> 7;
+    bool bad = false;
+    for (int j = 0; j < NB; ++j) {
+        const float d = a[j * 129 + j];
+        if (!(d > 0.0f) || !(d < 3.0e38f)) bad = true;
+        const float sd = sqrtf(d);
+        __syncthreads();   // everyone has read the pivot before it is overwritten
+        if (par == 0 && row >= j) a[row * 129 + j] = row == j ? sd : a[row * 129 + j] / sd;
+        __syncthreads();
+        if (row > j) {
+            const float lij = a[row * 129 + j];
+            for (int k = j + 1 + ((j + 1 + par) & 1); k <= row; k += 2) a[row * 129 + k] -= lij * a[k * 129 + j];
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) atomicOr(status, 1);
+
+    // L^-1 by forward substitution, one column of the inverse per thread (threads 0..127)
+    if (tid < NB) {
+        const int c = tid;
+        for (int i = 0; i < NB; ++i) {
+            float s = i == c ? 1.0f : 0.0f;
+            if (i >= c) {
+                for (int k = c; k < i; ++k) s -= a[i * 129 + k] * x[k * 129 + c];
+                s /= a[i * 129 + i];
+            } else {
+                s = 0.0f;
+            }
+            x[i * 129 + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        linv[(o + r) * ld + o + c] = x[r * 129 + c];
+    }
+}
+
+constexpr int LEAF_LDS = 2 * NB * 129 * 4;
+
+// (L, L^-1) of w[o:o+n, o:o+n]; n is a multiple of 128.
+int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *status, hipStream_t stream)
+{
+    if (n <= NB) {
+        hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), LEAF_LDS, stream, w, linv, ld, o, status);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    }
+    const int64_t n1 = ((n / NB) / 2) * NB, n2 = n - n1;
+    int rc = cholinv_rec(w, linv, ld, o, n1, status, stream);
+    if (rc) return rc;
+    float *a21 = w + (o + n1) * ld + o;          // B, later X = L21 L11^-1
+    float *a22 = w + (o + n1) * ld + o + n1;     // D
+    float *i11 = linv + o * ld + o;              // L11^-1
+    float *i21 = linv + (o + n1) * ld + o;       // scratch for L21, finally (L^-1)21
+    float *i22 = linv + (o + n1) * ld + o + n1;  // L22^-1
+    GqSgemmArgs g{};
+    g.lda = g.ldb = g.ldc = ld;
+    // L21 = B * L11^-T          out[i][j] = sum_k B[i][k] * L11inv[j][k],  k <= j
+    g.a = a21; g.b = i11; g.c = i21; g.m = (int)n2; g.n = (int)n1; g.k = (int)n1;
+    g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_K_LE_N; g.negate = 0; g.accumulate = 0; g.lower_only = 0;
+    if ((rc = gq_sgemm(g, stream))) return rc;
+    // D -= L21 * L21^T          lower tiles only
+    g.a = i21; g.b = i21; g.c = a22; g.m = (int)n2; g.n = (int)n2; g.k = (int)n1;
+    g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_NONE; g.negate = 1; g.accumulate = 1; g.lower_only = 1;
+    if ((rc = gq_sgemm(g, stream))) return rc;
+    if ((rc = cholinv_rec(w, linv, ld, o + n1, n2, status, stream))) return rc;
+    // X = L21 * L11^-1          out[i][j] = sum_k L21[i][k] * L11inv[k][j],  k >= j   (into B's place)
+    g.a = i21; g.b = i11; g.c = a21; g.m = (int)n2; g.n = (int)n1; g.k = (int)n1;
+    g.layout = GQ_A_MK | GQ_B_KN; g.trim = GQ_TRIM_K_GE_N; g.negate = 0; g.accumulate = 0; g.lower_only = 0;
+    if ((rc = gq_sgemm(g, stream))) return rc;
+    // (L^-1)21 = -L22^-1 * X    out[i][j] = -sum_k L22inv[i][k] * X[k][j],  k <= i
+    g.a = i22; g.b = a21; g.c = i21; g.m = (int)n2; g.n = (int)n1; g.k = (int)n2;
+    g.layout = GQ_A_MK | GQ_B_KN; g.trim = GQ_TRIM_K_LE_M; g.negate = 1; g.accumulate = 0; g.lower_only = 0;
+    return gq_sgemm(g, stream);
+}
+
+struct InvertWorkspace {
+    float *t;        // c * c     gather target
+    float *w;        // cp * cp   reversed work matrix
+    float *linv;     // cp * cp
+    float *diag;     // c
+    float *damp;     // 1
+    int *status;     // 1
+    int32_t *perm;   // c (used when the caller passes no perm buffer)
+    int32_t *perm_inv;
+};
+
+size_t carve(InvertWorkspace &ws, char *base, int64_t c)
+{
+    const int64_t cp = gq_round_up(c, NB);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    ws.t = (float *)take((size_t)c * c * 4);
+    ws.w = (float *)take((size_t)cp * cp * 4);
+    ws.linv = (float *)take((size_t)cp * cp * 4);
+    ws.diag = (float *)take((size_t)c * 4);
+    ws.damp = (float *)take(256);
+    ws.status = (int *)take(256);
+    ws.perm = (int32_t *)take((size_t)c * 4);
+    ws.perm_inv = (int32_t *)take((size_t)c * 4);
+    return off;
+}
+
+int ew_blocks(int64_t total) { return (int)std::min<int64_t>(gq_cdiv(total, 256), 256 * 16); }
+
+}  // namespace
+
+extern "C" size_t gq_hessian_invert_workspace(int64_t c)
+{
+    if (c <= 0) return 0;
+    InvertWorkspace ws;
+    return carve(ws, nullptr, c);
+}
+
+extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c,
+                                 double n_samples, float damp_ratio, int act_order, int max_try, void *workspace,
+                                 size_t workspace_bytes, int *tries_host, gq_stream_t stream_)
+{
+    GQ_REQUIRE(hessian && hessian_inv && workspace, "gq_hessian_invert: NULL pointer");
+    GQ_REQUIRE(c > 0 && c <= 32767 * 4, "gq_hessian_invert: bad size %lld", (long long)c);
+    GQ_REQUIRE(n_samples > 0, "gq_hessian_invert: n_samples must be positive");
+    GQ_REQUIRE(!act_order || (perm && perm_inv), "gq_hessian_invert: act_order needs perm and perm_inv buffers");
+    GQ_REQUIRE(max_try >= 1, "gq_hessian_invert: max_try must be >= 1");
+    GQ_REQUIRE((((uintptr_t)hessian | (uintptr_t)hessian_inv | (uintptr_t)workspace) & 15) == 0,
+               "gq_hessian_invert: pointers must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    InvertWorkspace ws;
+    const size_t need = carve(ws, (char *)workspace, c);
+    if (workspace_bytes < need) {
+        gq_set_error("gq_hessian_invert: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        return GQ_EWORKSPACE;
+    }
+    const int64_t cp = gq_round_up(c, NB);
+    const int64_t cc = c * c;
+
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, c, (float)(2.0 / n_samples), ws.diag);
+    GQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp);
+    GQ_LAUNCH_CHECK();
+    if (act_order) {
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 256)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
+        GQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, ws.t);
+        GQ_LAUNCH_CHECK();
+        GQ_HIP(hipMemcpyAsync(hessian, ws.t, (size_t)cc * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
+
+    int tries = 0;
+    while (tries < max_try) {
+        ++tries;
+        GQ_HIP(hipMemsetAsync(ws.status, 0, 256, stream));
+        GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
+        hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
+        GQ_LAUNCH_CHECK();
+        int rc = cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream);
+        if (rc) return rc;
+        int status = 0;
+        GQ_HIP(hipMemcpyAsync(&status, ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
+        GQ_HIP(hipStreamSynchronize(stream));
+        if (status == 0) {
+            hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv);
+            GQ_LAUNCH_CHECK();
+            GQ_HIP(hipStreamSynchronize(stream));
+            if (tries_host) *tries_host = tries;
+            return GQ_OK;
+        }
+    }
+    if (tries_host) *tries_host = tries;
+    gq_set_error("gq_hessian_invert: not positive definite after %d dampings", tries);
+    return GQ_ENOTPD;
+}

@@ -1,0 +1,171 @@
+// Bit packing of quantised rows, dequantisation back to a dense 16-bit weight (the reference's
+// reconstruct_nn_linear, quant.py:222-237, 262-279) and the activation column gather for
+// act-order.  All bandwidth-bound, one pass over the data, coalesced on the wide side.
+#include "gq_common.h"
+
+namespace {
+
+// nibble position of value v (0..7) inside a word in the GQ_PACK_W4_PAIRS layout
+__host__ __device__ __forceinline__ int w4_pairs_nibble(int v) { return (v & 1) * 4 + (v >> 1); }
+
+// one thread per output word
+__global__ void pack_kernel(const uint8_t *__restrict__ values, int64_t rows, int64_t n, int bits, int layout,
+                            int64_t words_per_row, uint32_t *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * words_per_row) return;
+    const int64_t row = i / words_per_row, wi = i - row * words_per_row;
+    const uint8_t *src = values + row * n;
+    uint32_t word = 0;
+    if (layout == GQ_PACK_W4_PAIRS) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int64_t idx = wi * 8 + v;
+            const uint32_t val = idx < n ? (src[idx] & 15u) : 0u;
+            word |= val << (4 * w4_pairs_nibble(v));
+        }
+    } else {
+        const int64_t bit0 = wi * 32;
+        int64_t first = bit0 / bits;                  // first value with bits in this word
+        for (int64_t idx = first; idx < n && idx * bits < bit0 + 32; ++idx) {
+            const uint64_t val = src[idx] & ((1u << bits) - 1u);
+            const int64_t sh = idx * bits - bit0;     // may be negative: value started in the previous word
+            word |= sh >= 0 ? (uint32_t)(val << sh) : (uint32_t)(val >> (-sh));
+        }
+    }
+    packed[i] = word;
+}
+
+// one thread per value
+__global__ void unpack_kernel(const uint32_t *__restrict__ packed, int64_t rows, int64_t n, int bits, int layout,
+                              int64_t words_per_row, uint8_t *__restrict__ values)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const int64_t row = i / n, idx = i - row * n;
+    const uint32_t *src = packed + row * words_per_row;
+    uint32_t val;
+    if (layout == GQ_PACK_W4_PAIRS) {
+        val = (src[idx >> 3] >> (4 * w4_pairs_nibble((int)(idx & 7)))) & 15u;
+    } else {
+        const int64_t bit = idx * bits, wi = bit >> 5;
+        const int sh = (int)(bit & 31);
+        uint64_t two = src[wi];
+        if (sh + bits > 32) two |= (uint64_t)src[wi + 1] << 32;
+        val = (uint32_t)(two >> sh) & ((1u << bits) - 1u);
+    }
+    values[i] = (uint8_t)val;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ unsigned short deq16(int q, int z, unsigned short s_raw)
+{
+    // (int16 q - int16 z) * scale evaluated in the 16-bit type: the integer difference is exact in
+    // either type, the product of two such values is exact in fp32, so one rounding = the
+    // correctly rounded 16-bit product.
+    const float d = (float)(q - z);
+    if constexpr (DTYPE == GQ_F16) {
+        const float s = (float)__builtin_bit_cast(_Float16, s_raw);
+        return __builtin_bit_cast(unsigned short, (_Float16)(d * s));
+    } else {
+        const float s = gq_bf16_to_f32(s_raw);
+        return __builtin_bit_cast(unsigned short, (__bf16)(d * s));
+    }
+}
+
+// One workgroup per row: the row of q (C bytes) is staged in LDS, then out[r][j] = deq(q[perm_inv[j]]).
+template <int DTYPE>
+__global__ __launch_bounds__(256) void dequant_kernel(const uint8_t *__restrict__ q, const unsigned short *__restrict__ scale,
+                                                      const uint8_t *__restrict__ zero, const int32_t *__restrict__ perm_inv,
+                                                      int64_t c, int n_groups, int group_size,
+                                                      const int32_t *__restrict__ col_group, unsigned short *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t *qrow = (uint8_t *)smem;
+    const int64_t r = blockIdx.x;
+    for (int64_t j = threadIdx.x; j < c; j += 256) qrow[j] = q[r * c + j];
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < c; j += 256) {
+        const int64_t k = perm_inv ? perm_inv[j] : j;
+        const int g = group_size > 0 ? (int)(k / group_size) : col_group[k];
+        out[r * c + j] = deq16<DTYPE>(qrow[k], zero[r * n_groups + g], scale[r * n_groups + g]);
+    }
+}
+
+// x_out[m][j] = x_in[m][perm[j]]; one workgroup per row, the row staged in LDS
+__global__ __launch_bounds__(256) void permute_cols_kernel(const unsigned short *__restrict__ x, const int32_t *__restrict__ perm,
+                                                           int64_t c, unsigned short *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short *row = (unsigned short *)smem;
+    const int64_t m = blockIdx.x;
+    for (int64_t j = threadIdx.x; j < c; j += 256) row[j] = x[m * c + j];
+    __syncthreads();
+    for (int64_t j = threadIdx.x; j < c; j += 256) out[m * c + j] = row[perm[j]];
+}
+
+}  // namespace
+
+extern "C" int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int bits, int layout, uint32_t *packed,
+                            gq_stream_t stream)
+{
+    GQ_REQUIRE(values && packed, "gq_pack_rows: NULL pointer");
+    GQ_REQUIRE(rows >= 0 && n >= 0, "gq_pack_rows: bad shape");
+    GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_pack_rows: bit width %d not in {2,3,4,8}", bits);
+    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4), "gq_pack_rows: bad layout %d for %d bits", layout, bits);
+    const int64_t wpr = gq_cdiv(n * bits, 32);
+    if (rows * wpr == 0) return GQ_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)gq_cdiv(rows * wpr, 256)), dim3(256), 0, (hipStream_t)stream, values, rows, n, bits, layout, wpr, packed);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_unpack_rows(const uint32_t *packed, int64_t rows, int64_t n, int bits, int layout, uint8_t *values,
+                              gq_stream_t stream)
+{
+    GQ_REQUIRE(values && packed, "gq_unpack_rows: NULL pointer");
+    GQ_REQUIRE(rows >= 0 && n >= 0, "gq_unpack_rows: bad shape");
+    GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_unpack_rows: bit width %d not in {2,3,4,8}", bits);
+    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4), "gq_unpack_rows: bad layout %d for %d bits", layout, bits);
+    const int64_t wpr = gq_cdiv(n * bits, 32);
+    if (rows * n == 0) return GQ_OK;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)gq_cdiv(rows * n, 256)), dim3(256), 0, (hipStream_t)stream, packed, rows, n, bits, layout, wpr, values);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_dequantize(const uint8_t *qweight, const void *scale, const uint8_t *qzero, const int32_t *perm_inv,
+                             int64_t r, int64_t c, int n_groups, int group_size, const int32_t *col_group, int dtype,
+                             void *weight_out, gq_stream_t stream)
+{
+    GQ_REQUIRE(qweight && scale && qzero && weight_out, "gq_dequantize: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_dequantize: bad dtype %d", dtype);
+    GQ_REQUIRE(r > 0 && c > 0 && n_groups > 0, "gq_dequantize: bad shape");
+    GQ_REQUIRE(c <= 160 * 1024, "gq_dequantize: a row of %lld columns does not fit in LDS", (long long)c);
+    GQ_REQUIRE((group_size > 0 && (int64_t)group_size * n_groups >= c) || (group_size == 0 && col_group),
+               "gq_dequantize: need a uniform group_size covering all columns, or group_size 0 with col_group");
+    const size_t lds = (size_t)((c + 15) & ~15);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GQ_F16) {
+        GQ_HIP(hipFuncSetAttribute((const void *)dequant_kernel<GQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dequant_kernel<GQ_F16>, dim3((unsigned)r), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
+    } else {
+        GQ_HIP(hipFuncSetAttribute((const void *)dequant_kernel<GQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dequant_kernel<GQ_BF16>, dim3((unsigned)r), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
+    }
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t c, void *x_out, gq_stream_t stream)
+{
+    GQ_REQUIRE(x_in && perm && x_out, "gq_permute_columns: NULL pointer");
+    GQ_REQUIRE(m >= 0 && c > 0 && c <= 80 * 1024, "gq_permute_columns: bad shape");
+    GQ_REQUIRE(x_in != x_out, "gq_permute_columns: in-place is not supported");
+    if (m == 0) return GQ_OK;
+    const size_t lds = (size_t)((c * 2 + 15) & ~15);
+    GQ_HIP(hipFuncSetAttribute((const void *)permute_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)m), dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_in, perm, c, (unsigned short *)x_out);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}

@@ -1,0 +1,609 @@
+// The GPTQ column loop on the device (reference: gptq_py.py:69-251, gptq_cpp.cpp:33-84,
+// gptq_cpp_kernel.cu:21-137) and the grid search that feeds it (quant.py:89-118).
+//
+// Working layout: everything is kept transposed, W^T as [C][R] fp32 ("one row per input
+// feature"), as the reference's native loop does.  One thread owns one output feature r, so
+// every access to column c of W is a coalesced read of row c of W^T and rows of W never
+// interact.  A block of up to 128 consecutive input features is processed per launch:
+//   * the thread loads its <=128 weights into registers (fully unrolled, static indices),
+//   * walks the columns in order: quantise, dequantise, error, and immediately applies the
+//     rank-1 update to the not-yet-quantised registers; the needed entries U[c][c'] are the same
+//     for every thread and come in through scalar loads,
+//   * nothing is written back but the outputs (q, dequantised value, scaled error).
+// The update of the columns behind the block is an fp32 MFMA GEMM (sgemm.hip) whose per-element
+// operation order (k ascending, fused multiply-add, starting from the old weight) is the same as
+// the in-block updates', so the result does not depend on how columns are cut into blocks.
+#include <vector>
+
+#include "sgemm.h"
+
+namespace {
+
+constexpr int QB = 128;   // max columns per block launch (registers per thread)
+struct QuantBlockArgs {
+    float *wt;               // [C][R] weights (read; rows a..a+bs-1 optionally written back)
+    float *quant_t;          // [C][R] or NULL
+    float *error_t;          // [C][R]
+    void *q_out;             // [C][R] int16 or uint8, or NULL
+    const float *u;          // [C][C]
+    float *scale;            // [R] grid of the group this block lies in (read, or written if dynamic)
+    float *zero;             // [R]
+    int64_t c, r;
+    int a, bs;
+    float maxq;
+    int q_is_u8;
+    int write_back;          // store the (updated) weights of the block back to wt
+    int dynamic;             // compute the grid here, from the block's weights as they are now
+    int sym;
+};
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fmaxf(lo, fminf(hi, x)); }
+
+__device__ __forceinline__ void grid_from_minmax(float lo, float hi, float amax, float maxq, int sym, float &scale,
+                                                 float &zero)
+{
+    if (sym) {
+        scale = amax * (2.0f / maxq) + 1e-12f;
+        zero = rintf((maxq + 1.0f) * 0.5f);
+    } else {
+        const float xmax = fmaxf(hi, 0.0f), xmin = fminf(lo, 0.0f);
+        scale = (xmax - xmin) / maxq + 1e-12f;
+        zero = rintf(-xmin / scale);
+    }
+}
+
+// SEM == GQ_SEM_KERNEL: fp16 dequantisation, fused update.  GQ_SEM_PYTHON: fp32, mul then sub.
+// The block's weights live in LDS as wl[column][lane] (one 4-byte column per lane: conflict-free);
+// SUB columns at a time are pulled into registers, walked sequentially, and their errors are then
+// applied to the rest of the block SUB columns at a time.  Every weight still sees its updates in
+// ascending column order, one fma each, so the cut into sub-blocks does not change any bit.
+// All pointers are separate __restrict__ kernel arguments so that the reads of U (same address in
+// every lane) are emitted as scalar loads.
+template <int SEM, int SUB>
+__global__ __launch_bounds__(64) void quant_block_kernel(
+    float *__restrict__ wt, float *__restrict__ quant_t, float *__restrict__ error_t, void *__restrict__ q_out,
+    const float *__restrict__ u, float *__restrict__ scale, float *__restrict__ zero, int64_t ldu, int64_t r_total,
+    int a, int bs, float maxq, int q_is_u8, int write_back, int dynamic, int sym)
+{
+    __shared__ float wl[QB][64];
+    const int lane = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = r < r_total;
+    const int64_t rr = live ? r : r_total - 1;   // dead lanes shadow the last row and store nothing
+    for (int c = 0; c < bs; ++c) wl[c][lane] = wt[(int64_t)(a + c) * r_total + rr];
+
+    float s, z;
+    if (dynamic) {
+        float lo = 3.4e38f, hi = -3.4e38f, am = 0.0f;
+        for (int c = 0; c < bs; ++c) {
+            const float v = wl[c][lane];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+            am = fmaxf(am, fabsf(v));
+        }
+        grid_from_minmax(lo, hi, am, maxq, sym, s, z);
+        if (live) {
+            scale[r] = s;
+            zero[r] = z;
+        }
+    } else {
+        s = scale[rr];
+        z = zero[rr];
+    }
+
+    const int n_sub = bs / SUB;
+    for (int jb = 0; jb < n_sub; ++jb) {
+        const int c0 = jb * SUB;                                  // first column of the sub-block
+        const float *__restrict__ urow = u + (int64_t)(a + c0) * ldu + a;   // urow[k*ldu + c'] = U[a+c0+k][a+c']
+        float w[SUB], nerr[SUB];
+#pragma unroll
+        for (int i = 0; i < SUB; ++i) w[i] = wl[c0 + i][lane];
+#pragma unroll
+        for (int i = 0; i < SUB; ++i) {
+            const float x = w[i];
+            const float qf = clampf(rintf(x / s) + z, 0.0f, maxq);
+            float deq;
+            if constexpr (SEM == GQ_SEM_KERNEL) {
+                const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
+                _Float16 hd = hx - hz;
+                hd = hd * hs;
+                deq = (float)hd;
+            } else {
+                deq = __fmul_rn(__fsub_rn(qf, z), s);
+            }
+            const float d = urow[(int64_t)i * ldu + c0 + i];
+            const float err = (x - deq) / d;
+            if (live) {
+                const int64_t o = (int64_t)(a + c0 + i) * r_total + r;
+                if (quant_t) quant_t[o] = deq;
+                error_t[o] = err;
+                if (q_out) {
+                    if (q_is_u8) ((uint8_t *)q_out)[o] = (uint8_t)qf;
+                    else ((int16_t *)q_out)[o] = (int16_t)(uint16_t)qf;
+                }
+                if (write_back) wt[o] = x;
+            }
+            nerr[i] = SEM == GQ_SEM_KERNEL ? -err : err;
+#pragma unroll
+            for (int i2 = i + 1; i2 < SUB; ++i2) {
+                const float uv = urow[(int64_t)i * ldu + c0 + i2];
+                if constexpr (SEM == GQ_SEM_KERNEL) w[i2] = fmaf(nerr[i], uv, w[i2]);
+                else w[i2] = __fsub_rn(w[i2], __fmul_rn(nerr[i], uv));
+            }
+        }
+        // the rest of the block, SUB columns at a time
+        for (int cb = jb + 1; cb < n_sub; ++cb) {
+            const int d0 = cb * SUB;
+            float v[SUB];
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) v[j] = wl[d0 + j][lane];
+#pragma unroll
+            for (int k = 0; k < SUB; ++k) {
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) {
+                    const float uv = urow[(int64_t)k * ldu + d0 + j];
+                    if constexpr (SEM == GQ_SEM_KERNEL) v[j] = fmaf(nerr[k], uv, v[j]);
+                    else v[j] = __fsub_rn(v[j], __fmul_rn(nerr[k], uv));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) wl[d0 + j][lane] = v[j];
+        }
+    }
+}
+
+// ---- grid for all groups from the unmodified weights (static groups) ------------------------
+__global__ void find_params_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0, int64_t ncols,
+                                   float maxq, int sym, float *__restrict__ scale, float *__restrict__ zero)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r_total) return;
+    float lo = 3.4e38f, hi = -3.4e38f, am = 0.0f;
+    for (int64_t c = col0; c < col0 + ncols; ++c) {
+        const float v = wt[c * r_total + r];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+        am = fmaxf(am, fabsf(v));
+    }
+    float sc, zr;
+    grid_from_minmax(lo, hi, am, maxq, sym, sc, zr);
+    scale[r] = sc;
+    zero[r] = zr;
+}
+
+// ---- W[R][C] (16-bit) -> W^T[C][R] fp32 with the act-order column gather ---------------------
+template <int DTYPE>
+__device__ __forceinline__ float to_f32(unsigned short raw)
+{
+    if constexpr (DTYPE == GQ_F16) return (float)__builtin_bit_cast(_Float16, raw);
+    else return gq_bf16_to_f32(raw);
+}
+
+// tile[jj][rr] = W[r0+rr][perm[j0+jj]]  (64 x 64), 256 threads
+template <int DTYPE>
+__device__ __forceinline__ void load_w_tile(float (*tile)[65], const unsigned short *__restrict__ w,
+                                            const int32_t *__restrict__ perm, int64_t r_total, int64_t c_total,
+                                            int64_t r0, int64_t j0)
+{
+    const int jj = threadIdx.x & 63;
+    const int64_t j = j0 + jj;
+    const int64_t src_col = j < c_total ? (perm ? perm[j] : j) : -1;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int rr = (threadIdx.x >> 6) + 4 * pass;
+        const int64_t r = r0 + rr;
+        float v = 0.0f;
+        if (src_col >= 0 && r < r_total) v = to_f32<DTYPE>(w[r * c_total + src_col]);
+        tile[jj][rr] = v;
+    }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(256) void prep_kernel(const unsigned short *__restrict__ w, const int32_t *__restrict__ perm,
+                                                   int64_t r_total, int64_t c_total, float *__restrict__ wt)
+{
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
+    __syncthreads();
+    const int rr = threadIdx.x & 63;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int jj = (threadIdx.x >> 6) + 4 * pass;
+        if (j0 + jj < c_total && r0 + rr < r_total) wt[(j0 + jj) * r_total + r0 + rr] = tile[jj][rr];
+    }
+}
+
+// ---- metrics ----------------------------------------------------------------------------------
+__device__ __forceinline__ void block_add(double v, double *dst, double *red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(dst, red[0]);
+    __syncthreads();
+}
+
+// sums[2] += (quant_t[j][r] - W[r][perm[j]])^2 over one 64x64 tile
+template <int DTYPE>
+__global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short *__restrict__ w,
+                                                           const int32_t *__restrict__ perm, int64_t r_total,
+                                                           int64_t c_total, const float *__restrict__ quant_t,
+                                                           double *__restrict__ sums)
+{
+    __shared__ float tile[64][65];
+    __shared__ double red[256];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+    load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
+    __syncthreads();
+    const int rr = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int pass = 0; pass < 16; ++pass) {
+        const int jj = (threadIdx.x >> 6) + 4 * pass;
+        if (j0 + jj < c_total && r0 + rr < r_total) {
+            const float d = quant_t[(j0 + jj) * r_total + r0 + rr] - tile[jj][rr];
+            acc += (double)d * (double)d;
+        }
+    }
+    block_add(acc, sums + 2, red);
+}
+
+// sums[0] += error^2 (flat), sums[1] += (W[r][j]/U[j][j])^2, sums[3] += W^2
+template <int DTYPE>
+__global__ __launch_bounds__(256) void metrics_flat_kernel(const unsigned short *__restrict__ w,
+                                                           const float *__restrict__ u, const float *__restrict__ error_t,
+                                                           int64_t r_total, int64_t c_total, double *__restrict__ sums)
+{
+    __shared__ double red[256];
+    const int64_t total = r_total * c_total;
+    double se = 0.0, sn = 0.0, sw = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (error_t) {
+            const float e = error_t[i];
+            se += (double)e * (double)e;
+        }
+        const float wv = to_f32<DTYPE>(w[i]);
+        // the reference squares in the weight's own 16-bit type (gptq_py.py:237): round each square
+        float sq;
+        if constexpr (DTYPE == GQ_F16) sq = (float)(_Float16)(wv * wv);
+        else sq = (float)(__bf16)(wv * wv);
+        sw += (double)sq;
+        if (u) {
+            const int64_t j = i % c_total;
+            const float q = wv / u[j * c_total + j];
+            sn += (double)q * (double)q;
+        }
+    }
+    block_add(se, sums + 0, red);
+    block_add(sn, sums + 1, red);
+    block_add(sw, sums + 3, red);
+}
+
+// ---- result collation -----------------------------------------------------------------------
+// q_t[C][R] uint8 -> qweight[R][C] uint8
+__global__ __launch_bounds__(256) void transpose_u8_kernel(const uint8_t *__restrict__ src, int64_t rows, int64_t cols,
+                                                           uint8_t *__restrict__ dst)
+{
+    __shared__ uint8_t tile[64][68];
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;   // src tile rows i0.., cols j0..
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int pass = 0; pass < 16; ++pass) {
+        const int ii = ty + 4 * pass;
+        if (i0 + ii < rows && j0 + tx < cols) tile[ii][tx] = src[(i0 + ii) * cols + j0 + tx];
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 16; ++pass) {
+        const int jj = ty + 4 * pass;
+        if (j0 + jj < cols && i0 + tx < rows) dst[(j0 + jj) * rows + i0 + tx] = tile[tx][jj];
+    }
+}
+
+// scale_g / zero_g [G][R] fp32 -> scale [R][G] (weight dtype), qzero [R][G] uint8
+template <int DTYPE>
+__global__ void collate_grid_kernel(const float *__restrict__ scale_g, const float *__restrict__ zero_g, int64_t r_total,
+                                    int n_groups, unsigned short *__restrict__ scale, uint8_t *__restrict__ qzero)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r_total * n_groups) return;
+    const int64_t g = i / r_total, r = i - g * r_total;
+    const float s = scale_g[i];
+    unsigned short raw;
+    if constexpr (DTYPE == GQ_F16) raw = __builtin_bit_cast(unsigned short, (_Float16)s);
+    else raw = __builtin_bit_cast(unsigned short, (__bf16)s);
+    scale[r * n_groups + g] = raw;
+    qzero[r * n_groups + g] = (uint8_t)zero_g[i];
+}
+
+// round-to-nearest: q and fp32 dequantised value, no error feedback (gptq_py.py:101-124)
+__global__ void rtn_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0, int64_t ncols, float maxq,
+                           const float *__restrict__ scale, const float *__restrict__ zero, uint8_t *__restrict__ q_t,
+                           float *__restrict__ quant_t)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r_total) return;
+    const float s = scale[r], z = zero[r];
+    for (int64_t c = col0; c < col0 + ncols; ++c) {
+        const float x = wt[c * r_total + r];
+        const float qf = clampf(rintf(x / s) + z, 0.0f, maxq);
+        q_t[c * r_total + r] = (uint8_t)qf;
+        if (quant_t) quant_t[c * r_total + r] = __fmul_rn(__fsub_rn(qf, z), s);
+    }
+}
+
+struct LayerWorkspace {
+    float *wt, *scale_g, *zero_g, *error_t;
+    uint8_t *q_t;
+};
+
+size_t carve_layer(LayerWorkspace &ws, char *base, int64_t r, int64_t c)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    ws.wt = (float *)take((size_t)r * c * 4);
+    ws.error_t = (float *)take((size_t)r * c * 4);
+    ws.q_t = (uint8_t *)take((size_t)r * c);
+    ws.scale_g = (float *)take((size_t)r * c);   // up to C/4 groups of >= 4 columns, 4 bytes each
+    ws.zero_g = (float *)take((size_t)r * c);
+    return off;
+}
+
+int check_groups(const int32_t *sizes, const int32_t *bits, int n_groups, int64_t c, const char *who)
+{
+    GQ_REQUIRE(sizes && bits && n_groups > 0, "%s: group description missing", who);
+    int64_t sum = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        GQ_REQUIRE(sizes[g] > 0 && sizes[g] % 4 == 0, "%s: group %d has size %d (must be a positive multiple of 4)", who, g, sizes[g]);
+        GQ_REQUIRE(bits[g] >= 1 && bits[g] <= 8, "%s: group %d has bit width %d (1..8 supported)", who, g, bits[g]);
+        sum += sizes[g];
+    }
+    GQ_REQUIRE(sum == c, "%s: group sizes sum to %lld, in_features is %lld", who, (long long)sum, (long long)c);
+    return GQ_OK;
+}
+
+template <int DTYPE>
+int launch_prep(const void *weight, const int32_t *perm, int64_t r, int64_t c, float *wt, hipStream_t stream)
+{
+    dim3 grid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
+    hipLaunchKernelGGL(prep_kernel<DTYPE>, grid, dim3(256), 0, stream, (const unsigned short *)weight, perm, r, c, wt);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+// largest launchable block that fits in `n` columns (n is a positive multiple of 4):
+// up to 128 columns in multiples of 16, else 8 or 4
+int block_size_for(int64_t n)
+{
+    if (n >= 16) return (int)std::min<int64_t>(QB, n - n % 16);
+    return n >= 8 ? 8 : 4;
+}
+
+int launch_block(const QuantBlockArgs &p, int semantics, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)gq_cdiv(p.r, 64);
+#define GQ_QB_LAUNCH(SEM, SUB)                                                                              \
+    hipLaunchKernelGGL((quant_block_kernel<SEM, SUB>), dim3(grid), dim3(64), 0, stream, p.wt, p.quant_t,      \
+                       p.error_t, p.q_out, p.u, p.scale, p.zero, p.c, p.r, p.a, p.bs, p.maxq, p.q_is_u8,      \
+                       p.write_back, p.dynamic, p.sym)
+    if (p.bs % 16 == 0) {
+        if (semantics == GQ_SEM_KERNEL) GQ_QB_LAUNCH(GQ_SEM_KERNEL, 16);
+        else GQ_QB_LAUNCH(GQ_SEM_PYTHON, 16);
+    } else {
+        if (semantics == GQ_SEM_KERNEL) GQ_QB_LAUNCH(GQ_SEM_KERNEL, 4);
+        else GQ_QB_LAUNCH(GQ_SEM_PYTHON, 4);
+    }
+#undef GQ_QB_LAUNCH
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+int trailing_update(const float *u, float *wt, const float *error_t, int64_t c, int64_t r, int64_t a, int64_t b,
+                    hipStream_t stream)
+{
+    if (b >= c) return GQ_OK;
+    GqSgemmArgs g{};
+    g.a = u + a * c + b;          // A[k][m] = U[a+k][b+m]
+    g.lda = c;
+    g.b = error_t + a * r;        // B[k][n] = E^T[a+k][n]
+    g.ldb = r;
+    g.c = wt + b * r;             // C[m][n] = W^T[b+m][n]
+    g.ldc = r;
+    g.m = (int)(c - b);
+    g.n = (int)r;
+    g.k = (int)(b - a);
+    g.layout = GQ_A_KM | GQ_B_KN;
+    g.trim = GQ_TRIM_NONE;
+    g.negate = 1;
+    g.accumulate = 1;
+    g.lower_only = 0;
+    return gq_sgemm(g, stream);
+}
+
+}  // namespace
+
+extern "C" int gq_find_params(const float *weights_t, int64_t c, int64_t r, int64_t col0, int64_t ncols, int bits,
+                              int sym, float *scale, float *qzero, gq_stream_t stream)
+{
+    GQ_REQUIRE(weights_t && scale && qzero, "gq_find_params: NULL pointer");
+    GQ_REQUIRE(c > 0 && r > 0 && col0 >= 0 && ncols > 0 && col0 + ncols <= c, "gq_find_params: bad column range");
+    GQ_REQUIRE(bits >= 1 && bits <= 16, "gq_find_params: bad bit width %d", bits);
+    const float maxq = (float)((1 << bits) - 1);
+    hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, (hipStream_t)stream, weights_t,
+                       r, col0, ncols, maxq, sym, scale, qzero);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_q, const float *qzero, float maxq,
+                                 const float *hessian_inv, float *weights, float *error, int64_t c, int64_t r,
+                                 int64_t a, int64_t b, gq_stream_t stream_)
+{
+    GQ_REQUIRE(quant && scale && qzero && hessian_inv && weights && error, "gq_quantize_range: NULL pointer");
+    GQ_REQUIRE(c > 0 && r > 0 && 0 <= a && a <= b && b <= c, "gq_quantize_range: bad range [%lld, %lld) of %lld",
+               (long long)a, (long long)b, (long long)c);
+    GQ_REQUIRE(r % 4 == 0 && c % 4 == 0 && (b - a) % 4 == 0 && a % 4 == 0,
+               "gq_quantize_range: out_features, in_features and the range must be multiples of 4");
+    hipStream_t stream = (hipStream_t)stream_;
+    // any range is cut into register-sized blocks; the result does not depend on the cut
+    for (int64_t s0 = a, s1; s0 < b; s0 = s1) {
+        s1 = s0 + block_size_for(b - s0);
+        QuantBlockArgs p{};
+        p.wt = weights; p.quant_t = quant; p.error_t = error; p.q_out = out_q; p.u = hessian_inv;
+        p.scale = const_cast<float *>(scale); p.zero = const_cast<float *>(qzero);
+        p.c = c; p.r = r; p.a = (int)s0; p.bs = (int)(s1 - s0); p.maxq = maxq;
+        p.q_is_u8 = 0; p.write_back = 1; p.dynamic = 0; p.sym = 0;
+        int rc = launch_block(p, GQ_SEM_KERNEL, stream);
+        if (rc) return rc;
+        // the reference updates rows [c+1, b) in its loop and rows [b, C) afterwards; both are this chain
+        if ((rc = trailing_update(hessian_inv, weights, error, c, r, s0, s1, stream))) return rc;
+    }
+    return GQ_OK;
+}
+
+extern "C" size_t gq_quantize_layer_workspace(int64_t r, int64_t c)
+{
+    if (r <= 0 || c <= 0) return 0;
+    LayerWorkspace ws;
+    return carve_layer(ws, nullptr, r, c);
+}
+
+extern "C" int gq_quantize_layer(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                                 int64_t r, int64_t c, const int32_t *group_sizes_host,
+                                 const int32_t *group_bits_host, int n_groups, int sym, int semantics,
+                                 uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t, float *error_t,
+                                 void *workspace, size_t workspace_bytes, gq_stream_t stream_)
+{
+    GQ_REQUIRE(weight && hessian_inv && qweight && scale && qzero && workspace, "gq_quantize_layer: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quantize_layer: bad dtype %d", dtype);
+    GQ_REQUIRE(semantics == GQ_SEM_KERNEL || semantics == GQ_SEM_PYTHON, "gq_quantize_layer: bad semantics %d", semantics);
+    GQ_REQUIRE(r > 0 && c > 0 && r % 4 == 0, "gq_quantize_layer: out_features %lld must be a positive multiple of 4", (long long)r);
+    int rc = check_groups(group_sizes_host, group_bits_host, n_groups, c, "gq_quantize_layer");
+    if (rc) return rc;
+    if (semantics == GQ_SEM_PYTHON)   // the grid is computed inside the block kernel: one block per group
+        for (int g = 0; g < n_groups; ++g)
+            GQ_REQUIRE(group_sizes_host[g] == block_size_for(group_sizes_host[g]),
+                       "gq_quantize_layer: python semantics supports groups of 4, 8 or 16..128 (multiple of 16) columns, got %d", group_sizes_host[g]);
+    LayerWorkspace ws;
+    const size_t need = carve_layer(ws, (char *)workspace, r, c);
+    if (workspace_bytes < need) {
+        gq_set_error("gq_quantize_layer: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        return GQ_EWORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    float *err = error_t ? error_t : ws.error_t;
+
+    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, r, c, ws.wt, stream)
+                         : launch_prep<GQ_BF16>(weight, perm, r, c, ws.wt, stream);
+    if (rc) return rc;
+
+    if (semantics == GQ_SEM_KERNEL) {   // grid of every group from the unmodified weights
+        int64_t col = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            const float maxq = (float)((1 << group_bits_host[g]) - 1);
+            hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, col,
+                               (int64_t)group_sizes_host[g], maxq, sym, ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r);
+            GQ_LAUNCH_CHECK();
+            col += group_sizes_host[g];
+        }
+    }
+
+    int64_t col = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const int64_t gend = col + group_sizes_host[g];
+        for (int64_t s0 = col, s1; s0 < gend; s0 = s1) {
+            s1 = s0 + block_size_for(gend - s0);
+            QuantBlockArgs p{};
+            p.wt = ws.wt; p.quant_t = quant_t; p.error_t = err; p.q_out = ws.q_t; p.u = hessian_inv;
+            p.scale = ws.scale_g + (int64_t)g * r; p.zero = ws.zero_g + (int64_t)g * r;
+            p.c = c; p.r = r; p.a = (int)s0; p.bs = (int)(s1 - s0);
+            p.maxq = (float)((1 << group_bits_host[g]) - 1);
+            p.q_is_u8 = 1; p.write_back = 0; p.dynamic = semantics == GQ_SEM_PYTHON; p.sym = sym;
+            if ((rc = launch_block(p, semantics, stream))) return rc;
+            if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, s0, s1, stream))) return rc;
+        }
+        col = gend;
+    }
+
+    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
+    hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
+    GQ_LAUNCH_CHECK();
+    const unsigned cg = (unsigned)gq_cdiv(r * n_groups, 256);
+    if (dtype == GQ_F16)
+        hipLaunchKernelGGL(collate_grid_kernel<GQ_F16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
+    else
+        hipLaunchKernelGGL(collate_grid_kernel<GQ_BF16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_quantize_rtn(const void *weight, int dtype, int64_t r, int64_t c, const int32_t *group_sizes_host,
+                               const int32_t *group_bits_host, int n_groups, int sym, uint8_t *qweight, void *scale,
+                               uint8_t *qzero, float *quant_t, void *workspace, size_t workspace_bytes,
+                               gq_stream_t stream_)
+{
+    GQ_REQUIRE(weight && qweight && scale && qzero && workspace, "gq_quantize_rtn: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quantize_rtn: bad dtype %d", dtype);
+    GQ_REQUIRE(r > 0 && c > 0, "gq_quantize_rtn: bad shape");
+    int rc = check_groups(group_sizes_host, group_bits_host, n_groups, c, "gq_quantize_rtn");
+    if (rc) return rc;
+    LayerWorkspace ws;
+    const size_t need = carve_layer(ws, (char *)workspace, r, c);
+    if (workspace_bytes < need) {
+        gq_set_error("gq_quantize_rtn: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        return GQ_EWORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, nullptr, r, c, ws.wt, stream)
+                         : launch_prep<GQ_BF16>(weight, nullptr, r, c, ws.wt, stream);
+    if (rc) return rc;
+    int64_t col = 0;
+    const unsigned rg = (unsigned)gq_cdiv(r, 256);
+    for (int g = 0; g < n_groups; ++g) {
+        const float maxq = (float)((1 << group_bits_host[g]) - 1);
+        float *sg = ws.scale_g + (int64_t)g * r, *zg = ws.zero_g + (int64_t)g * r;
+        hipLaunchKernelGGL(find_params_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, col, (int64_t)group_sizes_host[g], maxq, sym, sg, zg);
+        GQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rtn_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, col, (int64_t)group_sizes_host[g], maxq, sg, zg, ws.q_t, quant_t);
+        GQ_LAUNCH_CHECK();
+        col += group_sizes_host[g];
+    }
+    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
+    hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
+    GQ_LAUNCH_CHECK();
+    const unsigned cg = (unsigned)gq_cdiv(r * n_groups, 256);
+    if (dtype == GQ_F16)
+        hipLaunchKernelGGL(collate_grid_kernel<GQ_F16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
+    else
+        hipLaunchKernelGGL(collate_grid_kernel<GQ_BF16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                                const float *quant_t, const float *error_t, int64_t r, int64_t c, double *sums,
+                                gq_stream_t stream_)
+{
+    GQ_REQUIRE(weight && quant_t && sums, "gq_quant_metrics: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quant_metrics: bad dtype %d", dtype);
+    GQ_REQUIRE(r > 0 && c > 0, "gq_quant_metrics: bad shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    GQ_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), stream));
+    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
+    const unsigned fg = (unsigned)std::min<int64_t>(gq_cdiv(r * c, 256), 4096);
+    const unsigned short *w = (const unsigned short *)weight;
+    if (dtype == GQ_F16) {
+        hipLaunchKernelGGL(metrics_tile_kernel<GQ_F16>, tgrid, dim3(256), 0, stream, w, perm, r, c, quant_t, sums);
+        hipLaunchKernelGGL(metrics_flat_kernel<GQ_F16>, dim3(fg), dim3(256), 0, stream, w, hessian_inv, error_t, r, c, sums);
+    } else {
+        hipLaunchKernelGGL(metrics_tile_kernel<GQ_BF16>, tgrid, dim3(256), 0, stream, w, perm, r, c, quant_t, sums);
+        hipLaunchKernelGGL(metrics_flat_kernel<GQ_BF16>, dim3(fg), dim3(256), 0, stream, w, hessian_inv, error_t, r, c, sums);
+    }
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}

@@ -1,0 +1,209 @@
+// fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32: every output element is one
+// k-ascending fma chain).  128x128 tile per 256-thread workgroup, 2x2 waves of 64x64,
+// 32-deep k-steps staged global -> registers -> LDS (two LDS stages, one barrier per step; the
+// next step's global loads are issued before this step's MFMAs and written to LDS after them).
+//
+// LDS images, chosen by how the operand lies in memory so that global loads are 16-byte and
+// coalesced and fragment reads (one ds_read_b32 per lane per MFMA operand) are conflict-free:
+//   k-contiguous source (A_MK, B_NK): [128 rows][33 floats]   read at row*33 + k
+//   row-contiguous source (A_KM, B_KN): [32 k][128 floats]    read at k*128 + row
+#include "sgemm.h"
+
+namespace {
+
+constexpr int BT = 128;   // tile edge
+constexpr int BKS = 32;   // k-step
+constexpr int IMG_FLOATS = BT * 33;             // the larger of the two images
+constexpr int SG_STAGE_FLOATS = 2 * IMG_FLOATS;  // A + B
+constexpr int SG_LDS_BYTES = 2 * SG_STAGE_FLOATS * 4;
+
+struct Prefetch {
+    f32x4 v[4];
+};
+
+// k-contiguous source: rows of the tile are rows of the matrix.
+__device__ __forceinline__ void load_kcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
+                                             int n_rows, int k0, int k_hi, int tid)
+{
+    const int kq = (tid & 7) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = row0 + (tid >> 3) + 32 * pass;
+        const int k = k0 + kq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n_rows && k < k_hi) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)row * ld + k);
+        p.v[pass] = v;
+    }
+}
+
+__device__ __forceinline__ void store_kcontig(const Prefetch &p, float *img, int tid)
+{
+    const int kq = (tid & 7) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        float *d = img + ((tid >> 3) + 32 * pass) * 33 + kq;
+        d[0] = p.v[pass][0];
+        d[1] = p.v[pass][1];
+        d[2] = p.v[pass][2];
+        d[3] = p.v[pass][3];
+    }
+}
+
+// row-contiguous source: rows of memory are k, the tile's rows run along memory columns.
+__device__ __forceinline__ void load_rcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
+                                             int n_rows, int k0, int k_hi, int tid)
+{
+    const int rq = (tid & 31) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int k = k0 + (tid >> 5) + 8 * pass;
+        const int row = row0 + rq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n_rows && k < k_hi) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)k * ld + row);
+        p.v[pass] = v;
+    }
+}
+
+__device__ __forceinline__ void store_rcontig(const Prefetch &p, float *img, int tid)
+{
+    const int rq = (tid & 31) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+        *reinterpret_cast<f32x4 *>(img + ((tid >> 5) + 8 * pass) * 128 + rq) = p.v[pass];
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    constexpr bool A_KM = (LAYOUT & GQ_A_KM) != 0;
+    constexpr bool B_KN = (LAYOUT & GQ_B_KN) != 0;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    int tm, tn;
+    if (g.lower_only) {
+        const int bid = blockIdx.x;
+        int r = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= bid) ++r;
+        while (r * (r + 1) / 2 > bid) --r;
+        tm = r;
+        tn = bid - r * (r + 1) / 2;
+    } else {
+        tm = blockIdx.x / tiles_n;
+        tn = blockIdx.x % tiles_n;
+    }
+    const int m0 = tm * BT, n0 = tn * BT;
+
+    int k_lo = 0, k_hi = g.k;
+    if (g.trim == GQ_TRIM_K_LE_N) k_hi = min(g.k, (tn + 1) * BT);
+    else if (g.trim == GQ_TRIM_K_GE_N) k_lo = min(g.k, tn * BT);
+    else if (g.trim == GQ_TRIM_K_LE_M) k_hi = min(g.k, (tm + 1) * BT);
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = 0.0f;
+                if (g.accumulate) {
+                    const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int col = n0 + (wc * 2 + b) * 32 + li;
+                    if (row < g.m && col < g.n) v = g.c[(int64_t)row * g.ldc + col];
+                }
+                acc[a][b][e] = v;
+            }
+
+    const float sgn = g.negate ? -1.0f : 1.0f;
+    const int n_steps = (k_hi - k_lo + BKS - 1) / BKS;
+    Prefetch pa, pb;
+    auto gload = [&](int step) {
+        const int k0 = k_lo + step * BKS;
+        if constexpr (A_KM) load_rcontig(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
+        else load_kcontig(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
+        if constexpr (B_KN) load_rcontig(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
+        else load_kcontig(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
+    };
+    auto lstore = [&](int stage) {
+        float *ia = smem + stage * SG_STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+        if constexpr (A_KM) store_rcontig(pa, ia, tid);
+        else store_kcontig(pa, ia, tid);
+        if constexpr (B_KN) store_rcontig(pb, ib, tid);
+        else store_kcontig(pb, ib, tid);
+    };
+
+    if (n_steps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int step = 0; step < n_steps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < n_steps) gload(step + 1);
+        const float *ia = smem + cur * SG_STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+#pragma unroll 4
+        for (int s = 0; s < BKS / 2; ++s) {
+            const int k = 2 * s + lh;
+            float fa[2], fb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ra = (wr * 2 + u) * 32 + li, rb = (wc * 2 + u) * 32 + li;
+                fa[u] = sgn * (A_KM ? ia[k * 128 + ra] : ia[ra * 33 + k]);
+                fb[u] = B_KN ? ib[k * 128 + rb] : ib[rb * 33 + k];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (step + 1 < n_steps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int col = n0 + (wc * 2 + b) * 32 + li;
+                if (row < g.m && col < g.n) g.c[(int64_t)row * g.ldc + col] = acc[a][b][e];
+            }
+}
+
+}  // namespace
+
+int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
+{
+    GQ_REQUIRE(args.a && args.b && args.c, "sgemm: NULL operand");
+    GQ_REQUIRE(args.m >= 0 && args.n >= 0 && args.k >= 0, "sgemm: negative dimension");
+    GQ_REQUIRE(args.m % 4 == 0 && args.n % 4 == 0 && args.k % 4 == 0 && args.lda % 4 == 0 && args.ldb % 4 == 0 &&
+                   args.ldc % 4 == 0,
+               "sgemm: m=%d n=%d k=%d lda=%lld ldb=%lld ldc=%lld must all be multiples of 4", args.m, args.n, args.k,
+               (long long)args.lda, (long long)args.ldb, (long long)args.ldc);
+    GQ_REQUIRE((((uintptr_t)args.a | (uintptr_t)args.b | (uintptr_t)args.c) & 15) == 0, "sgemm: operands must be 16-byte aligned");
+    if (args.m == 0 || args.n == 0) return GQ_OK;
+    const int tiles_m = (args.m + BT - 1) / BT, tiles_n = (args.n + BT - 1) / BT;
+    GQ_REQUIRE(!args.lower_only || tiles_m == tiles_n, "sgemm: lower_only needs a square tile grid");
+    const int n_blocks = args.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    void (*kern)(GqSgemmArgs, int, int) = nullptr;
+    switch (args.layout) {
+    case GQ_A_MK | GQ_B_NK: kern = sgemm_kernel<GQ_A_MK | GQ_B_NK>; break;
+    case GQ_A_MK | GQ_B_KN: kern = sgemm_kernel<GQ_A_MK | GQ_B_KN>; break;
+    case GQ_A_KM | GQ_B_NK: kern = sgemm_kernel<GQ_A_KM | GQ_B_NK>; break;
+    case GQ_A_KM | GQ_B_KN: kern = sgemm_kernel<GQ_A_KM | GQ_B_KN>; break;
+    default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
+    }
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), SG_LDS_BYTES, stream, args, tiles_m, tiles_n);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}

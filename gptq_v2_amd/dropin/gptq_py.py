@@ -1,0 +1,2 @@
+"""Stands in for the reference's ``gptq_py.py``."""
+from gptq_v2_amd.gptq_py import GPTQ, HessianHook, gptq_quant  # noqa: F401

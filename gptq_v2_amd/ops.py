@@ -1,0 +1,262 @@
+"""Tensor-level wrappers over the C ABI (include/gptq_amd.h).
+
+PyTorch is used for device memory and streams only; every function validates its arguments
+(device, dtype, contiguity, shape) and then hands raw device pointers to libgptq_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+GQ_F16, GQ_BF16 = 0, 1
+SEM_KERNEL, SEM_PYTHON = 0, 1
+PACK_STREAM, PACK_W4_PAIRS = 0, 1
+
+_DTYPE_CODE = {torch.float16: GQ_F16, torch.bfloat16: GQ_BF16}
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise NotImplementedError(f"dtype {t.dtype}: only float16 and bfloat16 are supported") from None
+
+
+def _check(t: torch.Tensor, name: str, dtype=None, ndim=None) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if t.device.type != "cuda":
+        raise ValueError(f"{name}: must live on the GPU (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dimensions, got {t.dim()}")
+
+
+def _stream(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _int_array(vals: Sequence[int]):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def xtx_accumulate(hessian: torch.Tensor, x: torch.Tensor, save_lower_only: bool = False,
+                   compute_lower_only: bool = True) -> None:
+    """hessian (C, C) fp32 += x^T x for x (N, C) fp16/bf16, in place."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(x, "x", None, 2)
+    code = _dtype_code(x)
+    n, c = x.shape
+    if hessian.shape != (c, c):
+        raise ValueError(f"hessian is {tuple(hessian.shape)}, x has {c} columns")
+    if x.device != hessian.device:
+        raise ValueError("hessian and x are on different devices")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_xtx_accumulate(_p(hessian), _p(x), code, n, c, int(save_lower_only),
+                                           int(compute_lower_only), _stream(x))
+    _lib.check(rc, "gq_xtx_accumulate")
+
+
+def hessian_invert(hessian: torch.Tensor, n_samples: float, damp_ratio: float = 1e-2, act_order: bool = True,
+                   max_try: int = 100) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor], int]:
+    """In place on ``hessian`` (scaled, permuted, damped as the reference leaves it).
+    Returns (hessian_inv U, perm int32 | None, perm_inv int32 | None, tries)."""
+    _check(hessian, "hessian", torch.float32, 2)
+    c = hessian.shape[0]
+    if hessian.shape != (c, c):
+        raise ValueError("hessian must be square")
+    dev = hessian.device
+    lib = _lib.load()
+    u = torch.empty_like(hessian)
+    perm = torch.empty(c, dtype=torch.int32, device=dev) if act_order else None
+    perm_inv = torch.empty(c, dtype=torch.int32, device=dev) if act_order else None
+    ws_bytes = lib.gq_hessian_invert_workspace(c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    tries = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        rc = lib.gq_hessian_invert(_p(hessian), _p(u), _p(perm), _p(perm_inv), c, float(n_samples), float(damp_ratio),
+                                   int(act_order), int(max_try), _p(ws), ws_bytes, ctypes.byref(tries), _stream(hessian))
+    _lib.check(rc, "gq_hessian_invert")
+    return u, perm, perm_inv, tries.value
+
+
+def find_params(weights_t: torch.Tensor, col0: int, ncols: int, bits: int, sym: bool = False):
+    """weights_t (C, R) fp32 -> scale (R,), qzero (R,) fp32 over columns [col0, col0+ncols)."""
+    _check(weights_t, "weights_t", torch.float32, 2)
+    c, r = weights_t.shape
+    scale = torch.empty(r, dtype=torch.float32, device=weights_t.device)
+    qzero = torch.empty_like(scale)
+    with torch.cuda.device(weights_t.device):
+        rc = _lib.load().gq_find_params(_p(weights_t), c, r, col0, ncols, bits, int(sym), _p(scale), _p(qzero),
+                                        _stream(weights_t))
+    _lib.check(rc, "gq_find_params")
+    return scale, qzero
+
+
+def quantize_range(quant, scale, out_q, qzero, maxq, hessian_inv, weights, error, a, b) -> None:
+    """The reference's native op, same argument order (package/gptq/__init__.py:16-28)."""
+    for t, name in ((quant, "quant"), (scale, "scale"), (qzero, "qzero"), (hessian_inv, "hessian_inv"),
+                    (weights, "weights"), (error, "error")):
+        _check(t, name, torch.float32)
+    c, r = weights.shape
+    if hessian_inv.shape[1] != c:
+        raise RuntimeError("H shape mismatch")  # the reference's only check (gptq_cpp.cpp:49)
+    if quant.shape != (c, r) or error.shape != (c, r) or scale.shape != (r,) or qzero.shape != (r,):
+        raise ValueError("quantize_range: inconsistent shapes")
+    q_ptr = None
+    if out_q is not None and out_q.device.type != "meta":  # a meta tensor means "no integer output"
+        _check(out_q, "out_q", torch.int16)
+        q_ptr = out_q
+    with torch.cuda.device(weights.device):
+        rc = _lib.load().gq_quantize_range(_p(quant), _p(scale), _p(q_ptr), _p(qzero), float(maxq), _p(hessian_inv),
+                                           _p(weights), _p(error), c, r, int(a), int(b), _stream(weights))
+    _lib.check(rc, "gq_quantize_range")
+
+
+def quantize_layer(weight: torch.Tensor, perm: Optional[torch.Tensor], hessian_inv: Optional[torch.Tensor],
+                   group_sizes: Sequence[int], group_bits: Sequence[int], sym: bool = False,
+                   semantics: int = SEM_KERNEL, want_quant: bool = True, want_error: bool = True):
+    """weight (R, C) fp16/bf16 -> dict(qweight u8 (R,C), scale (R,G) weight dtype, qzero u8 (R,G),
+    quant_t fp32 (C,R) | None, error_t fp32 (C,R) | None).  hessian_inv None = round to nearest."""
+    _check(weight, "weight", None, 2)
+    code = _dtype_code(weight)
+    r, c = weight.shape
+    dev = weight.device
+    g = len(group_sizes)
+    if len(group_bits) != g:
+        raise ValueError("group_sizes and group_bit_widths differ in length")
+    lib = _lib.load()
+    qweight = torch.empty(r, c, dtype=torch.uint8, device=dev)
+    scale = torch.empty(r, g, dtype=weight.dtype, device=dev)
+    qzero = torch.empty(r, g, dtype=torch.uint8, device=dev)
+    quant_t = torch.empty(c, r, dtype=torch.float32, device=dev) if want_quant else None
+    ws_bytes = lib.gq_quantize_layer_workspace(r, c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    gs, gb = _int_array(group_sizes), _int_array(group_bits)
+    with torch.cuda.device(dev):
+        if hessian_inv is None:
+            error_t = None
+            rc = lib.gq_quantize_rtn(_p(weight), code, r, c, gs, gb, g, int(sym), _p(qweight), _p(scale), _p(qzero),
+                                     _p(quant_t), _p(ws), ws_bytes, _stream(weight))
+            _lib.check(rc, "gq_quantize_rtn")
+        else:
+            _check(hessian_inv, "hessian_inv", torch.float32, 2)
+            if hessian_inv.shape != (c, c):
+                raise RuntimeError("H shape mismatch")
+            if perm is not None:
+                _check(perm, "perm", torch.int32, 1)
+            error_t = torch.empty(c, r, dtype=torch.float32, device=dev) if want_error else None
+            rc = lib.gq_quantize_layer(_p(weight), code, _p(perm), _p(hessian_inv), r, c, gs, gb, g, int(sym),
+                                       int(semantics), _p(qweight), _p(scale), _p(qzero), _p(quant_t), _p(error_t),
+                                       _p(ws), ws_bytes, _stream(weight))
+            _lib.check(rc, "gq_quantize_layer")
+    return {"qweight": qweight, "scale": scale, "qzero": qzero, "quant_t": quant_t, "error_t": error_t}
+
+
+def quant_metrics(weight, perm, hessian_inv, quant_t, error_t) -> torch.Tensor:
+    """Returns the four sums (double, device) behind gptq_quant's metrics."""
+    _check(weight, "weight", None, 2)
+    r, c = weight.shape
+    sums = torch.empty(4, dtype=torch.float64, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.load().gq_quant_metrics(_p(weight), _dtype_code(weight), _p(perm), _p(hessian_inv), _p(quant_t),
+                                          _p(error_t), r, c, _p(sums), _stream(weight))
+    _lib.check(rc, "gq_quant_metrics")
+    return sums
+
+
+def dequantize(qweight: torch.Tensor, scale: torch.Tensor, qzero: torch.Tensor, perm_inv: Optional[torch.Tensor],
+               group_sizes: Sequence[int]) -> torch.Tensor:
+    """Dense (R, C) weight in scale's dtype, columns un-permuted (reconstruct_nn_linear's weight)."""
+    _check(qweight, "qweight", torch.uint8, 2)
+    _check(scale, "scale", None, 2)
+    _check(qzero, "qzero", torch.uint8, 2)
+    r, c = qweight.shape
+    g = scale.shape[1]
+    if scale.shape != (r, g) or qzero.shape != (r, g) or len(group_sizes) != g or sum(group_sizes) != c:
+        raise ValueError("dequantize: inconsistent shapes")
+    code = _dtype_code(scale)
+    dev = qweight.device
+    if perm_inv is not None:
+        _check(perm_inv, "perm_inv", torch.int32, 1)
+    uniform = all(s == group_sizes[0] for s in group_sizes)
+    col_group = None
+    if not uniform:
+        col_group = torch.repeat_interleave(torch.arange(g, dtype=torch.int32, device=dev),
+                                            torch.tensor(list(group_sizes), device=dev)).contiguous()
+    out = torch.empty(r, c, dtype=scale.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().gq_dequantize(_p(qweight), _p(scale), _p(qzero), _p(perm_inv), r, c, g,
+                                       int(group_sizes[0]) if uniform else 0, _p(col_group), code, _p(out),
+                                       _stream(qweight))
+    _lib.check(rc, "gq_dequantize")
+    return out
+
+
+def words_per_row(n: int, bits: int) -> int:
+    return (n * bits + 31) // 32
+
+
+def pack_rows(values: torch.Tensor, bits: int, layout: int = PACK_STREAM) -> torch.Tensor:
+    _check(values, "values", torch.uint8, 2)
+    rows, n = values.shape
+    out = torch.empty(rows, words_per_row(n, bits), dtype=torch.int32, device=values.device)
+    with torch.cuda.device(values.device):
+        rc = _lib.load().gq_pack_rows(_p(values), rows, n, bits, layout, _p(out), _stream(values))
+    _lib.check(rc, "gq_pack_rows")
+    return out
+
+
+def unpack_rows(packed: torch.Tensor, bits: int, n: int, layout: int = PACK_STREAM) -> torch.Tensor:
+    _check(packed, "packed", torch.int32, 2)
+    rows = packed.shape[0]
+    if packed.shape[1] != words_per_row(n, bits):
+        raise ValueError("unpack_rows: word count does not match n and bits")
+    out = torch.empty(rows, n, dtype=torch.uint8, device=packed.device)
+    with torch.cuda.device(packed.device):
+        rc = _lib.load().gq_unpack_rows(_p(packed), rows, n, bits, layout, _p(out), _stream(packed))
+    _lib.check(rc, "gq_unpack_rows")
+    return out
+
+
+def permute_columns(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    _check(x, "x", None, 2)
+    _check(perm, "perm", torch.int32, 1)
+    if x.element_size() != 2:
+        raise NotImplementedError("permute_columns: 16-bit elements only")
+    m, c = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_permute_columns(_p(x), _p(perm), m, c, _p(out), _stream(x))
+    _lib.check(rc, "gq_permute_columns")
+    return out
+
+
+def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale: torch.Tensor, qzero: torch.Tensor,
+               group_size: int) -> torch.Tensor:
+    """x (M, C) fp16, columns in permuted order -> y (M, R) fp16."""
+    _check(x, "x", torch.float16, 2)
+    _check(qweight_packed, "qweight_packed", torch.int32, 2)
+    _check(scale, "scale", torch.float16, 2)
+    _check(qzero, "qzero", torch.uint8, 2)
+    m, c = x.shape
+    r = qweight_packed.shape[0]
+    if qweight_packed.shape[1] * 8 != c or scale.shape != (r, c // group_size) or qzero.shape != scale.shape:
+        raise ValueError("w4a16_gemm: inconsistent shapes")
+    y = torch.empty(m, r, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_w4a16_gemm(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c, int(group_size),
+                                       _stream(x))
+    _lib.check(rc, "gq_w4a16_gemm")
+    return y

@@ -1,0 +1,166 @@
+/*
+ * gptq_amd.h -- C ABI of libgptq_amd.so: the GPTQ calibration / int4 inference hot path
+ * as hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all buffers are caller-allocated, dense and row-major; nothing is returned
+ *     except through them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous with respect to the host unless stated otherwise;
+ *   - return value: 0 on success, a negative GQ_E* code on error; gq_last_error()
+ *     returns a thread-local, human-readable description of the last failure;
+ *   - dtype codes: GQ_F16 = 0 (IEEE binary16), GQ_BF16 = 1.
+ *
+ * Citations "ref:" name the reference interface each entry point replaces
+ * (paths are relative to the 4PiR2/gptq-v2 checkout).
+ */
+#ifndef GPTQ_AMD_H
+#define GPTQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GQ_F16 0
+#define GQ_BF16 1
+
+#define GQ_OK 0
+#define GQ_EINVAL (-1)     /* bad argument (shape, dtype code, alignment, NULL) */
+#define GQ_EHIP (-2)       /* a HIP runtime call or kernel launch failed */
+#define GQ_ENOTPD (-3)     /* Hessian still not positive definite after max_try dampings */
+#define GQ_EWORKSPACE (-4) /* workspace too small */
+
+/* Semantics selector of the column loop (the reference has two, with different results). */
+#define GQ_SEM_KERNEL 0 /* ref: gptq_py.py:125-157 -- grid from the unmodified weights,
+                           fp16 dequantisation inside the loop, fused multiply-add updates */
+#define GQ_SEM_PYTHON 1 /* ref: gptq_py.py:158-193 -- grid from the error-compensated
+                           weights, fp32 dequantisation, separate multiply and subtract */
+
+typedef void *gq_stream_t;
+
+const char *gq_last_error(void);
+int gq_version(void);
+
+/* H[c][c] (fp32) += X^T X for X[n_tokens][hidden] (fp16 or bf16), fp32 accumulation.
+ * compute_lower_only != 0: only tiles on or below the diagonal are computed; unless
+ * save_lower_only != 0 each strictly-lower tile is also written, transposed, to its mirror
+ * position, so H comes out exactly symmetric.  save_lower_only requires compute_lower_only.
+ * ref: package/gptq/__init__.py:6-13, accumulate_hessian.cpp:20-45,
+ *      accumulate_hessian_kernel.cu:10-84 (full product: compute_lower_only = 0),
+ *      gptq_triton/accumulate_hessian.py:134-149 (save_lower_only / compute_lower_only). */
+int gq_xtx_accumulate(float *hessian, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
+                      int save_lower_only, int compute_lower_only, gq_stream_t stream);
+
+/* Bytes of workspace gq_hessian_invert needs for a C x C Hessian. */
+size_t gq_hessian_invert_workspace(int64_t c);
+
+/* The whole of HessianHook.invert on the device.  In place on `hessian`:
+ *   H *= 2/n_samples; H[i][i] = 1 where it is 0; if act_order: perm = argsort(diag, descending,
+ *   ties by index), H = H[perm][:, perm]; damp = damp_ratio * mean(diag);
+ *   repeat { H[i][i] += damp; factor } until the factorisation succeeds (at most max_try times).
+ * Outputs: hessian_inv = U, upper triangular (zeros below the diagonal), (H)^-1 = U^T U;
+ * perm / perm_inv (int32[c], written only if act_order; may be NULL otherwise);
+ * *tries_host = number of dampings applied.  U is obtained as the inverse of the factor of the
+ * index-reversed matrix (J H J = L L^T  =>  U = J L^-1 J), mathematically the factor the
+ * reference gets from cholesky -> cholesky_inverse -> cholesky(upper), at half the flops.
+ * A try fails when a pivot is <= 0 or not finite (the reference tests the result for NaN).
+ * Synchronous: returns after the stream has drained.
+ * ref: gptq_py.py:38-66. */
+int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv,
+                      int64_t c, double n_samples, float damp_ratio, int act_order, int max_try,
+                      void *workspace, size_t workspace_bytes, int *tries_host, gq_stream_t stream);
+
+/* Per-row quantisation grid over columns [col0, col0+ncols) of W^T stored as weights_t[C][R]:
+ * asymmetric (sym = 0): scale = (max(x,0) - min(x,0)) / maxq + 1e-12, qzero = round(-min/scale);
+ * symmetric: scale = max|x| * 2/maxq + 1e-12, qzero = (maxq+1)/2.   maxq = 2^bits - 1.
+ * ref: quant.py:89-118 (without the EXL2 scale quantisation). */
+int gq_find_params(const float *weights_t, int64_t c, int64_t r, int64_t col0, int64_t ncols, int bits,
+                   int sym, float *scale, float *qzero, gq_stream_t stream);
+
+/* Columns [a, b) of the GPTQ loop with the reference's native argument order and layouts:
+ * quant, weights, error are [C][R] fp32 (weights updated in place, rows > a), out_q is [C][R]
+ * int16 or NULL, scale/qzero are [R] fp32, hessian_inv is U [C][C].
+ * Per column c: x = clamp(rint(w/s)+z, 0, maxq); q = half(half(x)-half(z))*half(s);
+ * e = (w-q)/U[c][c]; w[c'] = fma(-e, U[c][c'], w[c']) for every c' > c (ascending c).
+ * ref: package/gptq/__init__.py:16-28, gptq_cpp.cpp:33-84, gptq_cpp_kernel.cu:21-158. */
+int gq_quantize_range(float *quant, const float *scale, int16_t *out_q, const float *qzero, float maxq,
+                      const float *hessian_inv, float *weights, float *error, int64_t c, int64_t r,
+                      int64_t a, int64_t b, gq_stream_t stream);
+
+/* Bytes of workspace gq_quantize_layer needs. */
+size_t gq_quantize_layer_workspace(int64_t r, int64_t c);
+
+/* gptq_quant for one Linear, both loop semantics, all on the device.
+ * weight[R][C] (fp16/bf16); perm int32[C] or NULL; hessian_inv U[C][C];
+ * group_sizes_host / group_bits_host: n_groups ints each, sum(group_sizes) == C.
+ * Outputs: qweight uint8[R][C] (permuted column order), scale [R][G] in the weight's dtype,
+ * qzero uint8[R][G], quant_t / error_t fp32 [C][R] (dequantised weights and scaled errors,
+ * transposed, permuted order; either may be NULL).
+ * ref: gptq_py.py:69-251 (prologue :86-96, loops :125-193, collation :216-229). */
+int gq_quantize_layer(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                      int64_t r, int64_t c, const int32_t *group_sizes_host,
+                      const int32_t *group_bits_host, int n_groups, int sym, int semantics,
+                      uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t, float *error_t,
+                      void *workspace, size_t workspace_bytes, gq_stream_t stream);
+
+/* Round-to-nearest quantisation without a Hessian (same outputs as gq_quantize_layer;
+ * error is identically zero in the reference and is not produced).
+ * ref: gptq_py.py:101-124. */
+int gq_quantize_rtn(const void *weight, int dtype, int64_t r, int64_t c,
+                    const int32_t *group_sizes_host, const int32_t *group_bits_host, int n_groups,
+                    int sym, uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t,
+                    void *workspace, size_t workspace_bytes, gq_stream_t stream);
+
+/* Sums behind gptq_quant's four metrics, accumulated in double:
+ *   sums[0] = sum(error^2), sums[1] = sum((W[r][j] / U[j][j])^2) (W unpermuted, as the reference
+ *   writes it), sums[2] = sum((quant[r][j] - W[r][perm[j]])^2), sums[3] = sum(W^2) with every
+ *   square rounded to the weight's 16-bit type first, as the reference computes it.
+ * `sums` (double[4], device) is zeroed by the call.  error_t / hessian_inv may be NULL (their
+ * sums stay 0).  The caller divides by R*C.
+ * ref: gptq_py.py:195-200, 231-238. */
+int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                     const float *quant_t, const float *error_t, int64_t r, int64_t c, double *sums,
+                     gq_stream_t stream);
+
+/* weight_out[R][C] (fp16/bf16) = ((int16)q - (int16)z) * scale per group, evaluated in the output
+ * dtype, then columns un-permuted: out[:, j] = deq[:, perm_inv[j]] (perm_inv int32[C] or NULL).
+ * Groups: uniform group_size > 0, or group_size == 0 and col_group (int32[C], device) giving the
+ * group index of every (permuted) column.
+ * ref: quant.py:222-237 (construct_matrix), quant.py:262-279 (reconstruct_nn_linear). */
+int gq_dequantize(const uint8_t *qweight, const void *scale, const uint8_t *qzero,
+                  const int32_t *perm_inv, int64_t r, int64_t c, int n_groups, int group_size,
+                  const int32_t *col_group, int dtype, void *weight_out, gq_stream_t stream);
+
+#define GQ_PACK_STREAM 0      /* value i at bits [i*bits, i*bits+bits) of the row's bit stream */
+#define GQ_PACK_W4_PAIRS 1    /* 4-bit only: within each uint32, values 0..7 sit in nibbles
+                                 0,4,1,5,2,6,3,7, so (w >> 4p) & 0x000F000F yields the value pair
+                                 (2p, 2p+1) in the two 16-bit halves -- the W4A16 GEMM operand */
+
+/* Packing of rows of `bits`-wide values (2, 3, 4 or 8) into uint32 words,
+ * words_per_row = ceil(n*bits/32), rows padded with zero bits.
+ * No reference counterpart (the reference stores one value per byte, gptq_py.py:217). */
+int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int bits, int layout,
+                 uint32_t *packed, gq_stream_t stream);
+int gq_unpack_rows(const uint32_t *packed, int64_t rows, int64_t n, int bits, int layout,
+                   uint8_t *values, gq_stream_t stream);
+
+/* x_out[m][j] = x_in[m][perm[j]] for 16-bit elements (activation gather for act-order). */
+int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t c, void *x_out,
+                       gq_stream_t stream);
+
+/* y[M][R] (fp16) = x[M][C] (fp16, columns already in permuted order) * W^T with
+ * W[r][k] = half(q[r][k] - z[r][g(k)]) * scale[r][g(k)] taken from 4-bit packed rows
+ * (GQ_PACK_W4_PAIRS layout, C/8 words per row), uniform group size, fp32 accumulation.
+ * Fills the slot of the dense fp16 nn.Linear at llama.py:172-177. */
+int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
+                  const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size,
+                  gq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTQ_AMD_H */
