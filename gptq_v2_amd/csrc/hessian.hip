@@ -123,59 +123,216 @@ __global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64
 // ---- 128x128 leaf: L = chol(A) and L^-1, one workgroup, everything in LDS ------------------
 // Reads the lower triangle of w[o:o+128, o:o+128]; writes the full 128x128 block of linv (zeros
 // above the diagonal).  A pivot that is not a positive finite number raises *status.
+//
+// Cholesky: 8 panels of 16 columns.  Per panel (a) one wave factors the 16x16 diagonal block and
+// inverts it with the rows on lanes and every broadcast a v_readlane (no LDS, no barrier),
+// (b) 112 row-threads form their 16 entries of the panel as  A21 * L11^-T  from the broadcast
+// inverse, (c) all 256 threads apply the rank-16 update to the trailing lower triangle in 4x4
+// register tiles.  Inverse: the 16x16 diagonal inverses are doubled three times,
+// inv([A 0; B D]) = [A^-1 0; -D^-1 (B A^-1) D^-1], again in 4x4 register tiles.
+constexpr int LLD = 132;                 // LDS row stride (floats): 16-byte aligned rows, 16 rows cover all banks
+constexpr int PB = 16;                   // panel width
+constexpr int SLD = 68;                  // stride of the 64x64 product scratch
+constexpr int LEAF_LDS = (2 * NB * LLD + 64 * SLD + PB * PB) * 4;
+
+// v_readlane on a float (the builtin is typed int: pass the bits, not the value)
+__device__ __forceinline__ float readlane_f32(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// lower-triangular tile index t -> (ti, tj), ti >= tj
+__device__ __forceinline__ void tri_index(int t, int &ti, int &tj)
+{
+    int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    while (r * (r + 1) / 2 > t) --r;
+    ti = r;
+    tj = t - r * (r + 1) / 2;
+}
+
 __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, float *__restrict__ linv, int64_t ld,
                                                    int64_t o, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *a = reinterpret_cast<float *>(smem_raw);   // [128][129]  A, then L
-    float *x = a + NB * 129;                          // [128][129]  L^-1, x[k][c]
+    float *a = reinterpret_cast<float *>(smem_raw);   // [128][LLD]  A, becomes L
+    float *x = a + NB * LLD;                          // [128][LLD]  L^-1
+    float *sc = x + NB * LLD;                         // [64][SLD]   product scratch
+    float *tinv = sc + 64 * SLD;                      // [16][16]    inverse of the current diagonal block
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        a[r * 129 + c] = c <= r ? w[(o + r) * ld + o + c] : 0.0f;
+    for (int e = tid; e < NB * (NB / 4); e += 256) {
+        const int r = e >> 5, c4 = (e & 31) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(w + (o + r) * ld + o + c4);
+        st4(a + r * LLD + c4, v);
+        st4(x + r * LLD + c4, f32x4{0.f, 0.f, 0.f, 0.f});
     }
     __syncthreads();
-
-    // right-looking Cholesky; thread t owns row (t & 127) and the columns of parity (t >> 7)
-    const int row = tid & 127, par = tid >> 7;
     bool bad = false;
-    for (int j = 0; j < NB; ++j) {
-        const float d = a[j * 129 + j];
-        if (!(d > 0.0f) || !(d < 3.0e38f)) bad = true;
-        const float sd = sqrtf(d);
-        __syncthreads();   // everyone has read the pivot before it is overwritten
-        if (par == 0 && row >= j) a[row * 129 + j] = row == j ? sd : a[row * 129 + j] / sd;
-        __syncthreads();
-        if (row > j) {
-            const float lij = a[row * 129 + j];
-            for (int k = j + 1 + ((j + 1 + par) & 1); k <= row; k += 2) a[row * 129 + k] -= lij * a[k * 129 + j];
-        }
-        __syncthreads();
-    }
-    if (bad && tid == 0) atomicOr(status, 1);
 
-    // L^-1 by forward substitution, one column of the inverse per thread (threads 0..127)
-    if (tid < NB) {
-        const int c = tid;
-        for (int i = 0; i < NB; ++i) {
-            float s = i == c ? 1.0f : 0.0f;
-            if (i >= c) {
-                for (int k = c; k < i; ++k) s -= a[i * 129 + k] * x[k * 129 + c];
-                s /= a[i * 129 + i];
-            } else {
-                s = 0.0f;
+    for (int p = 0; p < NB / PB; ++p) {
+        const int c0 = p * PB, c1 = c0 + PB;
+        // (a) diagonal block: lane i (< 16) of wave 0 holds row i
+        if (tid < 64) {
+            const int i = tid & 15;
+            float d[PB];
+#pragma unroll
+            for (int k4 = 0; k4 < PB; k4 += 4) {
+                const f32x4 v = lds4(a + (c0 + i) * LLD + c0 + k4);
+                d[k4] = v[0]; d[k4 + 1] = v[1]; d[k4 + 2] = v[2]; d[k4 + 3] = v[3];
             }
-            x[i * 129 + c] = s;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const float dj = readlane_f32(d[j], j);
+                if (!(dj > 0.0f) || !(dj < 3.0e38f)) bad = true;
+                const float sj = sqrtf(dj);
+                const float lj = i == j ? sj : d[j] / sj;
+                d[j] = lj;
+#pragma unroll
+                for (int k = j + 1; k < PB; ++k) d[k] = fmaf(-lj, readlane_f32(lj, k), d[k]);
+            }
+            // inverse: lane c holds column c, xi[i] = (L11^-1)[i][c]
+            float xi[PB];
+#pragma unroll
+            for (int r = 0; r < PB; ++r) {
+                float sacc = i == r ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < r; ++k) sacc = fmaf(-readlane_f32(d[k], r), xi[k], sacc);
+                xi[r] = sacc / readlane_f32(d[r], r);
+            }
+            if (tid < PB) {
+#pragma unroll
+                for (int k4 = 0; k4 < PB; k4 += 4) {
+                    // zero the strict upper part so that later full-row reads see a clean triangle
+                    f32x4 v;
+                    v[0] = k4 <= i ? d[k4] : 0.f; v[1] = k4 + 1 <= i ? d[k4 + 1] : 0.f;
+                    v[2] = k4 + 2 <= i ? d[k4 + 2] : 0.f; v[3] = k4 + 3 <= i ? d[k4 + 3] : 0.f;
+                    st4(a + (c0 + i) * LLD + c0 + k4, v);
+                }
+#pragma unroll
+                for (int r = 0; r < PB; ++r) {
+                    tinv[r * PB + i] = xi[r];
+                    x[(c0 + r) * LLD + c0 + i] = xi[r];
+                }
+            }
         }
+        __syncthreads();
+        // (b) panel below the diagonal block: row t of  A21 * L11^-T
+        if (tid < NB && tid >= c1) {
+            float ar[PB], out[PB];
+#pragma unroll
+            for (int k4 = 0; k4 < PB; k4 += 4) {
+                const f32x4 v = lds4(a + tid * LLD + c0 + k4);
+                ar[k4] = v[0]; ar[k4 + 1] = v[1]; ar[k4 + 2] = v[2]; ar[k4 + 3] = v[3];
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
+                out[j] = sacc;
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < PB; k4 += 4) st4(a + tid * LLD + c0 + k4, f32x4{out[k4], out[k4 + 1], out[k4 + 2], out[k4 + 3]});
+        }
+        __syncthreads();
+        // (c) trailing lower triangle -= L21 L21^T, 4x4 tiles
+        const int nt = (NB - c1) / 4;
+        for (int t = tid; t < nt * (nt + 1) / 2; t += 256) {
+            int ti, tj;
+            tri_index(t, ti, tj);
+            const int r0 = c1 + 4 * ti, q0 = c1 + 4 * tj;
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = lds4(a + (r0 + u) * LLD + q0);
+#pragma unroll
+            for (int k4 = 0; k4 < PB; k4 += 4) {
+                f32x4 lr[4], lc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lr[u] = lds4(a + (r0 + u) * LLD + c0 + k4);
+                    lc[u] = lds4(a + (q0 + u) * LLD + c0 + k4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[u][v] = fmaf(-lr[u][k], lc[v][k], acc[u][v]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) st4(a + (r0 + u) * LLD + q0, acc[u]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        linv[(o + r) * ld + o + c] = x[r * 129 + c];
+    if (__syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
+
+    // inverse by doubling: blocks of size s at b and b+s -> X21 = -X22 * (L21 * X11)
+    for (int s = PB; s < NB; s *= 2) {
+        const int tiles_per_dim = s / 4, tiles_per_pair = tiles_per_dim * tiles_per_dim;
+        const int n_pairs = NB / (2 * s);
+        // pass 1: T = L21 * X11  (X11 lower triangular: k >= column)
+        for (int t = tid; t < n_pairs * tiles_per_pair; t += 256) {
+            const int pair = t / tiles_per_pair, tt = t % tiles_per_pair;
+            const int ti = tt / tiles_per_dim, tj = tt % tiles_per_dim;
+            const int b = pair * 2 * s;
+            const float *l21 = a + (b + s + 4 * ti) * LLD + b;
+            const float *x11 = x + b * LLD + b + 4 * tj;
+            f32x4 acc[4] = {};
+            for (int k = 4 * tj; k < s; k += 4) {
+                f32x4 lr[4], xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lr[u] = lds4(l21 + u * LLD + k);
+                    xr[u] = lds4(x11 + (k + u) * LLD);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(lr[u][kk], xr[kk][v], acc[u][v]);
+            }
+            float *dst = sc + (pair * s + 4 * ti) * SLD + 4 * tj;   // pairs stacked by rows: n_pairs * s <= 64 rows
+#pragma unroll
+            for (int u = 0; u < 4; ++u) st4(dst + u * SLD, acc[u]);
+        }
+        __syncthreads();
+        // pass 2: X21 = -X22 * T  (X22 lower triangular: k <= row)
+        for (int t = tid; t < n_pairs * tiles_per_pair; t += 256) {
+            const int pair = t / tiles_per_pair, tt = t % tiles_per_pair;
+            const int ti = tt / tiles_per_dim, tj = tt % tiles_per_dim;
+            const int b = pair * 2 * s;
+            const float *x22 = x + (b + s + 4 * ti) * LLD + b + s;
+            const float *tm = sc + (pair * s) * SLD + 4 * tj;
+            f32x4 acc[4] = {};
+            for (int k = 0; k <= 4 * ti; k += 4) {
+                f32x4 xr[4], tr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xr[u] = lds4(x22 + u * LLD + k);
+                    tr[u] = lds4(tm + (k + u) * SLD);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(-xr[u][kk], tr[kk][v], acc[u][v]);
+            }
+            float *dst = x + (b + s + 4 * ti) * LLD + b + 4 * tj;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) st4(dst + u * LLD, acc[u]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < NB * (NB / 4); e += 256) {
+        const int r = e >> 5, c4 = (e & 31) * 4;
+        *reinterpret_cast<f32x4 *>(linv + (o + r) * ld + o + c4) = lds4(x + r * LLD + c4);
     }
 }
-
-constexpr int LEAF_LDS = 2 * NB * 129 * 4;
 
 // (L, L^-1) of w[o:o+n, o:o+n]; n is a multiple of 128.
 int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *status, hipStream_t stream)

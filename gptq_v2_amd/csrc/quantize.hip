@@ -53,24 +53,43 @@ __device__ __forceinline__ void grid_from_minmax(float lo, float hi, float amax,
 }
 
 // SEM == GQ_SEM_KERNEL: fp16 dequantisation, fused update.  GQ_SEM_PYTHON: fp32, mul then sub.
-// The block's weights live in LDS as wl[column][lane] (one 4-byte column per lane: conflict-free);
-// SUB columns at a time are pulled into registers, walked sequentially, and their errors are then
-// applied to the rest of the block SUB columns at a time.  Every weight still sees its updates in
-// ascending column order, one fma each, so the cut into sub-blocks does not change any bit.
-// All pointers are separate __restrict__ kernel arguments so that the reads of U (same address in
-// every lane) are emitted as scalar loads.
+//
+// One 256-thread workgroup owns 64 output features (lane = feature) and one block of <= 128
+// columns.  LDS holds the block's weights wl[column][lane] (one 4-byte column per lane: conflict-
+// free) and the block's square of U, ul[c][c'], whose reads are the same address in every lane
+// (broadcast).  SUB columns at a time are pulled into registers and walked sequentially by ALL
+// four waves redundantly (the other SIMDs would idle anyway, and every wave then owns the SUB
+// scaled errors without any exchange); the rank-SUB update of the rest of the block is split
+// over the waves SUB columns at a time.  Every weight still sees its updates in ascending column
+// order, one fma each, so the cut into sub-blocks does not change any bit.
+constexpr int ULD = QB + 4;   // stride of the U square in LDS
+constexpr int QB_LDS = (QB * 64 + QB * ULD) * 4;
+
 template <int SEM, int SUB>
-__global__ __launch_bounds__(64) void quant_block_kernel(
+__global__ __launch_bounds__(256) void quant_block_kernel(
     float *__restrict__ wt, float *__restrict__ quant_t, float *__restrict__ error_t, void *__restrict__ q_out,
     const float *__restrict__ u, float *__restrict__ scale, float *__restrict__ zero, int64_t ldu, int64_t r_total,
     int a, int bs, float maxq, int q_is_u8, int write_back, int dynamic, int sym)
 {
-    __shared__ float wl[QB][64];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float (*wl)[64] = reinterpret_cast<float (*)[64]>(smem_raw);
+    float *ul = reinterpret_cast<float *>(smem_raw) + QB * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 64 + lane;
     const bool live = r < r_total;
     const int64_t rr = live ? r : r_total - 1;   // dead lanes shadow the last row and store nothing
-    for (int c = 0; c < bs; ++c) wl[c][lane] = wt[(int64_t)(a + c) * r_total + rr];
+    for (int c = wv; c < bs; c += 4) wl[c][lane] = wt[(int64_t)(a + c) * r_total + rr];
+    {
+        const int q4 = bs / 4;   // float4 per row of the square
+        for (int e = tid; e < bs * q4; e += 256) {
+            const int row = e / q4, c4 = (e - row * q4) * 4;
+            *reinterpret_cast<f32x4 *>(ul + row * ULD + c4) =
+                *reinterpret_cast<const f32x4 *>(u + (int64_t)(a + row) * ldu + a + c4);
+        }
+    }
+    __syncthreads();
 
     float s, z;
     if (dynamic) {
@@ -82,7 +101,7 @@ __global__ __launch_bounds__(64) void quant_block_kernel(
             am = fmaxf(am, fabsf(v));
         }
         grid_from_minmax(lo, hi, am, maxq, sym, s, z);
-        if (live) {
+        if (live && wv == 0) {
             scale[r] = s;
             zero[r] = z;
         }
@@ -90,49 +109,59 @@ __global__ __launch_bounds__(64) void quant_block_kernel(
         s = scale[rr];
         z = zero[rr];
     }
+    const bool writer = live && wv == 0;
 
     const int n_sub = bs / SUB;
     for (int jb = 0; jb < n_sub; ++jb) {
-        const int c0 = jb * SUB;                                  // first column of the sub-block
-        const float *__restrict__ urow = u + (int64_t)(a + c0) * ldu + a;   // urow[k*ldu + c'] = U[a+c0+k][a+c']
-        float w[SUB], nerr[SUB];
+        const int c0 = jb * SUB;   // first column of the sub-block
+        float w[SUB], nerr[SUB], deq[SUB], qv[SUB];
 #pragma unroll
         for (int i = 0; i < SUB; ++i) w[i] = wl[c0 + i][lane];
 #pragma unroll
         for (int i = 0; i < SUB; ++i) {
             const float x = w[i];
             const float qf = clampf(rintf(x / s) + z, 0.0f, maxq);
-            float deq;
+            float dq;
             if constexpr (SEM == GQ_SEM_KERNEL) {
                 const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
                 _Float16 hd = hx - hz;
                 hd = hd * hs;
-                deq = (float)hd;
+                dq = (float)hd;
             } else {
-                deq = __fmul_rn(__fsub_rn(qf, z), s);
+                dq = __fmul_rn(__fsub_rn(qf, z), s);
             }
-            const float d = urow[(int64_t)i * ldu + c0 + i];
-            const float err = (x - deq) / d;
-            if (live) {
-                const int64_t o = (int64_t)(a + c0 + i) * r_total + r;
-                if (quant_t) quant_t[o] = deq;
-                error_t[o] = err;
-                if (q_out) {
-                    if (q_is_u8) ((uint8_t *)q_out)[o] = (uint8_t)qf;
-                    else ((int16_t *)q_out)[o] = (int16_t)(uint16_t)qf;
-                }
-                if (write_back) wt[o] = x;
-            }
+            const float d = ul[(c0 + i) * ULD + c0 + i];
+            const float err = (x - dq) / d;
+            qv[i] = qf;
+            deq[i] = dq;
             nerr[i] = SEM == GQ_SEM_KERNEL ? -err : err;
 #pragma unroll
             for (int i2 = i + 1; i2 < SUB; ++i2) {
-                const float uv = urow[(int64_t)i * ldu + c0 + i2];
+                const float uv = ul[(c0 + i) * ULD + c0 + i2];
                 if constexpr (SEM == GQ_SEM_KERNEL) w[i2] = fmaf(nerr[i], uv, w[i2]);
                 else w[i2] = __fsub_rn(w[i2], __fmul_rn(nerr[i], uv));
             }
         }
-        // the rest of the block, SUB columns at a time
-        for (int cb = jb + 1; cb < n_sub; ++cb) {
+        if (writer) {
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                const int64_t o = (int64_t)(a + c0 + i) * r_total + r;
+                error_t[o] = SEM == GQ_SEM_KERNEL ? -nerr[i] : nerr[i];
+                if (quant_t) quant_t[o] = deq[i];
+                if (write_back) wt[o] = w[i];
+            }
+            if (q_out) {
+                if (q_is_u8) {
+#pragma unroll
+                    for (int i = 0; i < SUB; ++i) ((uint8_t *)q_out)[(int64_t)(a + c0 + i) * r_total + r] = (uint8_t)qv[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SUB; ++i) ((int16_t *)q_out)[(int64_t)(a + c0 + i) * r_total + r] = (int16_t)(uint16_t)qv[i];
+                }
+            }
+        }
+        // the rest of the block, SUB columns at a time, one chunk per wave
+        for (int cb = jb + 1 + wv; cb < n_sub; cb += 4) {
             const int d0 = cb * SUB;
             float v[SUB];
 #pragma unroll
@@ -140,15 +169,19 @@ __global__ __launch_bounds__(64) void quant_block_kernel(
 #pragma unroll
             for (int k = 0; k < SUB; ++k) {
 #pragma unroll
-                for (int j = 0; j < SUB; ++j) {
-                    const float uv = urow[(int64_t)k * ldu + d0 + j];
-                    if constexpr (SEM == GQ_SEM_KERNEL) v[j] = fmaf(nerr[k], uv, v[j]);
-                    else v[j] = __fsub_rn(v[j], __fmul_rn(nerr[k], uv));
+                for (int j4 = 0; j4 < SUB; j4 += 4) {
+                    const f32x4 uv = *reinterpret_cast<const f32x4 *>(ul + (c0 + k) * ULD + d0 + j4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (SEM == GQ_SEM_KERNEL) v[j4 + e] = fmaf(nerr[k], uv[e], v[j4 + e]);
+                        else v[j4 + e] = __fsub_rn(v[j4 + e], __fmul_rn(nerr[k], uv[e]));
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < SUB; ++j) wl[d0 + j][lane] = v[j];
         }
+        __syncthreads();
     }
 }
 
@@ -387,10 +420,14 @@ int block_size_for(int64_t n)
 int launch_block(const QuantBlockArgs &p, int semantics, hipStream_t stream)
 {
     const unsigned grid = (unsigned)gq_cdiv(p.r, 64);
-#define GQ_QB_LAUNCH(SEM, SUB)                                                                              \
-    hipLaunchKernelGGL((quant_block_kernel<SEM, SUB>), dim3(grid), dim3(64), 0, stream, p.wt, p.quant_t,      \
-                       p.error_t, p.q_out, p.u, p.scale, p.zero, p.c, p.r, p.a, p.bs, p.maxq, p.q_is_u8,      \
-                       p.write_back, p.dynamic, p.sym)
+#define GQ_QB_LAUNCH(SEM, SUB)                                                                                   \
+    do {                                                                                                         \
+        GQ_HIP(hipFuncSetAttribute((const void *)quant_block_kernel<SEM, SUB>,                                  \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, QB_LDS));                        \
+        hipLaunchKernelGGL((quant_block_kernel<SEM, SUB>), dim3(grid), dim3(256), QB_LDS, stream, p.wt,          \
+                           p.quant_t, p.error_t, p.q_out, p.u, p.scale, p.zero, p.c, p.r, p.a, p.bs, p.maxq,     \
+                           p.q_is_u8, p.write_back, p.dynamic, p.sym);                                           \
+    } while (0)
     if (p.bs % 16 == 0) {
         if (semantics == GQ_SEM_KERNEL) GQ_QB_LAUNCH(GQ_SEM_KERNEL, 16);
         else GQ_QB_LAUNCH(GQ_SEM_PYTHON, 16);
@@ -403,26 +440,47 @@ int launch_block(const QuantBlockArgs &p, int semantics, hipStream_t stream)
     return GQ_OK;
 }
 
-int trailing_update(const float *u, float *wt, const float *error_t, int64_t c, int64_t r, int64_t a, int64_t b,
-                    hipStream_t stream)
+// W^T[m0:m1] -= U[k0:k1, m0:m1]^T * E^T[k0:k1]   (k ascending, fused, starting from the old weight)
+int trailing_update(const float *u, float *wt, const float *error_t, int64_t c, int64_t r, int64_t k0, int64_t k1,
+                    int64_t m0, int64_t m1, hipStream_t stream)
 {
-    if (b >= c) return GQ_OK;
+    if (m0 >= m1 || k0 >= k1) return GQ_OK;
     GqSgemmArgs g{};
-    g.a = u + a * c + b;          // A[k][m] = U[a+k][b+m]
+    g.a = u + k0 * c + m0;        // A[k][m] = U[k0+k][m0+m]
     g.lda = c;
-    g.b = error_t + a * r;        // B[k][n] = E^T[a+k][n]
+    g.b = error_t + k0 * r;       // B[k][n] = E^T[k0+k][n]
     g.ldb = r;
-    g.c = wt + b * r;             // C[m][n] = W^T[b+m][n]
+    g.c = wt + m0 * r;            // C[m][n] = W^T[m0+m][n]
     g.ldc = r;
-    g.m = (int)(c - b);
+    g.m = (int)(m1 - m0);
     g.n = (int)r;
-    g.k = (int)(b - a);
+    g.k = (int)(k1 - k0);
     g.layout = GQ_A_KM | GQ_B_KN;
     g.trim = GQ_TRIM_NONE;
     g.negate = 1;
     g.accumulate = 1;
     g.lower_only = 0;
     return gq_sgemm(g, stream);
+}
+
+// all groups' grids in one launch when group size and bit width are uniform
+__global__ void find_params_all_kernel(const float *__restrict__ wt, int64_t r_total, int group_size, float maxq, int sym,
+                                       float *__restrict__ scale_g, float *__restrict__ zero_g)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r_total) return;
+    const int64_t g = blockIdx.y, col0 = g * group_size;
+    float lo = 3.4e38f, hi = -3.4e38f, am = 0.0f;
+    for (int64_t c = col0; c < col0 + group_size; ++c) {
+        const float v = wt[c * r_total + r];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+        am = fmaxf(am, fabsf(v));
+    }
+    float sc, zr;
+    grid_from_minmax(lo, hi, am, maxq, sym, sc, zr);
+    scale_g[g * r_total + r] = sc;
+    zero_g[g * r_total + r] = zr;
 }
 
 }  // namespace
@@ -461,7 +519,7 @@ extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_
         int rc = launch_block(p, GQ_SEM_KERNEL, stream);
         if (rc) return rc;
         // the reference updates rows [c+1, b) in its loop and rows [b, C) afterwards; both are this chain
-        if ((rc = trailing_update(hessian_inv, weights, error, c, r, s0, s1, stream))) return rc;
+        if ((rc = trailing_update(hessian_inv, weights, error, c, r, s0, s1, s1, c, stream))) return rc;
     }
     return GQ_OK;
 }
@@ -503,31 +561,63 @@ extern "C" int gq_quantize_layer(const void *weight, int dtype, const int32_t *p
     if (rc) return rc;
 
     if (semantics == GQ_SEM_KERNEL) {   // grid of every group from the unmodified weights
-        int64_t col = 0;
-        for (int g = 0; g < n_groups; ++g) {
-            const float maxq = (float)((1 << group_bits_host[g]) - 1);
-            hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, col,
-                               (int64_t)group_sizes_host[g], maxq, sym, ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r);
+        bool uniform = true;
+        for (int g = 1; g < n_groups; ++g)
+            uniform = uniform && group_sizes_host[g] == group_sizes_host[0] && group_bits_host[g] == group_bits_host[0];
+        if (uniform) {
+            dim3 grid((unsigned)gq_cdiv(r, 256), (unsigned)n_groups);
+            hipLaunchKernelGGL(find_params_all_kernel, grid, dim3(256), 0, stream, ws.wt, r, (int)group_sizes_host[0],
+                               (float)((1 << group_bits_host[0]) - 1), sym, ws.scale_g, ws.zero_g);
             GQ_LAUNCH_CHECK();
-            col += group_sizes_host[g];
+        } else {
+            int64_t col = 0;
+            for (int g = 0; g < n_groups; ++g) {
+                const float maxq = (float)((1 << group_bits_host[g]) - 1);
+                hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, col,
+                                   (int64_t)group_sizes_host[g], maxq, sym, ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r);
+                GQ_LAUNCH_CHECK();
+                col += group_sizes_host[g];
+            }
         }
     }
 
-    int64_t col = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        const int64_t gend = col + group_sizes_host[g];
-        for (int64_t s0 = col, s1; s0 < gend; s0 = s1) {
-            s1 = s0 + block_size_for(gend - s0);
+    // Blocks of <= 128 columns, never across a group boundary, gathered into super-blocks of about
+    // SUPER columns: after each block only the columns up to the end of its super-block are updated
+    // (short GEMM, K = block), the columns behind the super-block once per super-block (K = SUPER).
+    // Each weight still receives its updates in ascending column order.
+    struct Blk { int64_t s0, s1; int g; };
+    std::vector<Blk> blocks;
+    {
+        int64_t col = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            const int64_t gend = col + group_sizes_host[g];
+            for (int64_t s0 = col, s1; s0 < gend; s0 = s1) {
+                s1 = s0 + block_size_for(gend - s0);
+                blocks.push_back({s0, s1, g});
+            }
+            col = gend;
+        }
+    }
+    constexpr int64_t SUPER = 512;
+    for (size_t i = 0; i < blocks.size();) {
+        size_t j = i;
+        const int64_t sup0 = blocks[i].s0;
+        while (j < blocks.size() && blocks[j].s1 - sup0 < SUPER) ++j;
+        const size_t last = std::min(j, blocks.size() - 1);
+        const int64_t sup1 = blocks[last].s1;
+        for (size_t b = i; b <= last; ++b) {
+            const Blk &bk = blocks[b];
             QuantBlockArgs p{};
             p.wt = ws.wt; p.quant_t = quant_t; p.error_t = err; p.q_out = ws.q_t; p.u = hessian_inv;
-            p.scale = ws.scale_g + (int64_t)g * r; p.zero = ws.zero_g + (int64_t)g * r;
-            p.c = c; p.r = r; p.a = (int)s0; p.bs = (int)(s1 - s0);
-            p.maxq = (float)((1 << group_bits_host[g]) - 1);
+            p.scale = ws.scale_g + (int64_t)bk.g * r; p.zero = ws.zero_g + (int64_t)bk.g * r;
+            p.c = c; p.r = r; p.a = (int)bk.s0; p.bs = (int)(bk.s1 - bk.s0);
+            p.maxq = (float)((1 << group_bits_host[bk.g]) - 1);
             p.q_is_u8 = 1; p.write_back = 0; p.dynamic = semantics == GQ_SEM_PYTHON; p.sym = sym;
             if ((rc = launch_block(p, semantics, stream))) return rc;
-            if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, s0, s1, stream))) return rc;
+            if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, bk.s0, bk.s1, bk.s1, sup1, stream))) return rc;
         }
-        col = gend;
+        if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, sup0, sup1, sup1, c, stream))) return rc;
+        i = last + 1;
     }
 
     dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
