@@ -21,21 +21,24 @@
 //   * only tiles with tile_row >= tile_col are launched in lower-only mode; blockIdx is remapped
 //     so that each XCD (blocks b, b+8, ... share one) walks a contiguous run of the triangular
 //     tile order and re-uses X panels from its own L2.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "gq_common.h"
 
 namespace {
 
 constexpr int TM = 128;        // output tile edge
-constexpr int BK = 64;         // tokens per k-step
-constexpr int OP_BYTES = BK * TM * 2;     // one operand tile in LDS: 16 KiB
-constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A and B
-constexpr int XTX_LDS = 2 * STAGE_BYTES;   // two stages: 64 KiB
 
-// One operand tile (64 tokens x 128 columns of 16-bit) into LDS by LDS-DMA: 16 wave-instructions
-// of 1 KiB (= 4 token rows), 4 per wave.  LDS position P (bytes) holds
+// One operand tile (BKT tokens x 128 columns of 16-bit) into LDS by LDS-DMA: BKT/4 wave-instructions
+// of 1 KiB (= 4 token rows), BKT/16 per wave.  LDS position P (bytes) holds
 //   token  k = P / 256,   32-byte chunk (P % 256) / 32  ^  2 * (k & 3),   half (P / 16) & 1.
+template <int BKT>
 __device__ __forceinline__ void stage_operand(const unsigned short *__restrict__ x, int64_t ld,
                                               int64_t tok0, int col0, char *lds_op, int wave, int lane)
 {
@@ -44,8 +47,8 @@ __device__ __forceinline__ void stage_operand(const unsigned short *__restrict__
     const int chunk = (s >> 1) ^ (2 * krow);
     const int coff = chunk * 16 + (s & 1) * 8;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int ii = wave * 4 + it;       // wave-uniform instruction index 0..15
+    for (int it = 0; it < BKT / 16; ++it) {
+        const int ii = wave * (BKT / 16) + it;       // wave-uniform instruction index
         const unsigned short *src = x + (tok0 + ii * 4 + krow) * ld + col0 + coff;
         __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_op + ii * 1024), 16, 0, 0);
     }
@@ -75,15 +78,15 @@ struct Frags {
     s16x4 a[2][2], b[2][2];
 };
 
-template <int BASE>
+template <int BASE, int OPB>
 __device__ __forceinline__ void read_step(Frags &f, const unsigned (&addrA)[2], const unsigned (&addrB)[2])
 {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         tr_read<BASE>(f.a[u][0], addrA[u]);
         tr_read<BASE + 4 * 256>(f.a[u][1], addrA[u]);
-        tr_read<BASE + OP_BYTES>(f.b[u][0], addrB[u]);
-        tr_read<BASE + OP_BYTES + 4 * 256>(f.b[u][1], addrB[u]);
+        tr_read<BASE + OPB>(f.b[u][0], addrB[u]);
+        tr_read<BASE + OPB + 4 * 256>(f.b[u][1], addrB[u]);
     }
 }
 
@@ -115,18 +118,28 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int lower, int &t
     }
 }
 
-template <int DTYPE>
+// BKT tokens per k-step, NST LDS stages: the DMA of step k + NST - 1 is issued right after the
+// barrier of step k (its buffer was read during step k - 1), so NST - 1 steps of loads are in
+// flight under the MFMAs; each wave waits only for its own loads of the step it is about to read
+// (counted vmcnt), then the barrier makes every wave's share visible.
+template <int DTYPE, int BKT, int NST>
 __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
-                                                       int hidden, int n_ktiles, int nt, int n_blocks,
-                                                       int compute_lower, int mirror)
+                                                       int hidden, int n_ktiles, const uint32_t *__restrict__ tile_table,
+                                                       int n_blocks, int mirror)
 {
+    constexpr int OP_BYTES = BKT * TM * 2;
+    constexpr int STAGE_BYTES = 2 * OP_BYTES;
+    constexpr int LPS = 2 * (BKT / 16);   // LDS-DMA instructions per wave per step
+    constexpr int KK = BKT / 16;          // MFMA k-steps per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
 
     // XCD-aware remap (bijective for any grid size): blocks with equal blockIdx % 8 share an XCD
-    // and get a contiguous range of logical tile ids.
+    // and get a contiguous range of the tile table, which lists the tiles super-tile by super-tile
+    // (see build_tile_table): the ~100 tiles an XCD has in flight then touch ~20 column panels of
+    // X instead of all of them, and X streams from HBM once per super-tile instead of once per row.
     int bid;
     {
         const int orig = blockIdx.x;
@@ -134,8 +147,8 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
         const int q = n_blocks >> 3, r = n_blocks & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    int ti, tj;
-    tile_of_block(bid, nt, compute_lower, ti, tj);
+    const uint32_t packed_tile = tile_table[bid];
+    const int ti = (int)(packed_tile >> 16), tj = (int)(packed_tile & 0xffffu);
     const int m0 = ti * TM, n0 = tj * TM;
     const int64_t ld = hidden;
 
@@ -161,50 +174,76 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
-    stage_operand(x, ld, 0, m0, smem, wave, lane);
-    stage_operand(x, ld, 0, n0, smem + OP_BYTES, wave, lane);
+    auto issue = [&](int kt, char *buf) {
+        stage_operand<BKT>(x, ld, (int64_t)kt * BKT, m0, buf, wave, lane);
+        stage_operand<BKT>(x, ld, (int64_t)kt * BKT, n0, buf + OP_BYTES, wave, lane);
+    };
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < n_ktiles) issue(st, smem + st * STAGE_BYTES);
 
-    // One barrier per k-step: after it every wave's DMA for stage `cur` has landed (each wave
-    // waited for its own) and every wave has finished reading the other stage (it completed its
-    // lgkmcnt(0) before arriving), so the other stage is restaged right away and its DMA flies
-    // under this step's reads and MFMAs.  Two steps per trip keep all LDS offsets immediates.
+    // All LDS offsets are immediates: the k-loop is unrolled NST times with the stage a constant.
     auto step = [&](auto cur_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
         constexpr int SB = cur * STAGE_BYTES;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n_ktiles - 1 - kt >= NST - 2) {
+            if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr ((NST - 2) * LPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr ((NST - 2) * LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr ((NST - 2) * LPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr ((NST - 2) * LPS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < n_ktiles) {
-            char *nxt = smem + (cur ^ 1) * STAGE_BYTES;
-            stage_operand(x, ld, (int64_t)(kt + 1) * BK, m0, nxt, wave, lane);
-            stage_operand(x, ld, (int64_t)(kt + 1) * BK, n0, nxt + OP_BYTES, wave, lane);
-        }
+        if (kt + NST - 1 < n_ktiles) issue(kt + NST - 1, smem + ((cur + NST - 1) % NST) * STAGE_BYTES);
+        // stage base goes into the address registers (ds offsets are 16-bit)
+        const unsigned sA[2] = {addrA[0] + SB, addrA[1] + SB}, sB[2] = {addrB[0] + SB, addrB[1] + SB};
         Frags f0, f1;
-        read_step<SB + 0 * 16 * 256>(f0, addrA, addrB);
-        read_step<SB + 1 * 16 * 256>(f1, addrA, addrB);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        read_step<0, OP_BYTES>(f0, sA, sB);
+        if constexpr (KK == 2) {
+            read_step<4096, OP_BYTES>(f1, sA, sB);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f1);
+        } else {
+            static_assert(KK == 4 || KK == 2, "32 or 64 tokens per step");
+            read_step<4096, OP_BYTES>(f1, sA, sB);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_step<2 * 4096, OP_BYTES>(f0, sA, sB);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_step<3 * 4096, OP_BYTES>(f1, sA, sB);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<DTYPE>(acc, f1);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step<DTYPE>(acc, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_step<SB + 2 * 16 * 256>(f0, addrA, addrB);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<DTYPE>(acc, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_step<SB + 3 * 16 * 256>(f1, addrA, addrB);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<DTYPE>(acc, f0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step<DTYPE>(acc, f1);
     };
     int kt = 0;
-    for (; kt + 1 < n_ktiles; kt += 2) {
+    for (; kt + NST <= n_ktiles; kt += NST) {
         step(std::integral_constant<int, 0>{}, kt);
-        step(std::integral_constant<int, 1>{}, kt + 1);
+        step(std::integral_constant<int, 1 % NST>{}, kt + 1);
+        if constexpr (NST > 2) step(std::integral_constant<int, 2 % NST>{}, kt + 2);
+        if constexpr (NST > 3) step(std::integral_constant<int, 3 % NST>{}, kt + 3);
     }
-    if (kt < n_ktiles) step(std::integral_constant<int, 0>{}, kt);   // odd step count: stage 0 is next
+    // remainder: fewer than NST steps left, stages continue from 0
+    if (kt < n_ktiles) step(std::integral_constant<int, 0>{}, kt++);
+    if (NST > 2 && kt < n_ktiles) step(std::integral_constant<int, 1 % NST>{}, kt++);
+    if (NST > 3 && kt < n_ktiles) step(std::integral_constant<int, 2 % NST>{}, kt++);
 
     // epilogue: H tile += acc; strictly-lower tiles are also written to their mirror position
     const bool do_mirror = mirror && (ti != tj);
@@ -216,6 +255,172 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + lrow;
+                const int col = n0 + (wc * 2 + b) * 32 + lcol;
+                float *p = hess + (int64_t)row * ld + col;
+                const float v = *p + acc[a][b][e];
+                *p = v;
+                if (do_mirror) hess[(int64_t)col * ld + row] = v;
+            }
+}
+
+// ---- 256 x 256 tiles -------------------------------------------------------------------------
+// Same construction with half the L2 -> LDS bytes per flop: 512 threads, 8 waves as 2 (rows) x 4
+// (columns), each wave a 128 x 64 sub-tile (4 x 2 MFMA blocks, 128 accumulator registers), 32-token
+// steps, 4 LDS stages of 32 KiB (one workgroup per CU, three steps of DMA in flight).
+// LDS rows are 512 bytes (256 columns); the 32-byte chunk index is XOR-ed with 2 * (k & 3) as in
+// the 128-column image (only the low three bits matter for the banks).
+constexpr int T2 = 256;
+constexpr int BK2 = 32;
+constexpr int NST2 = 4;
+constexpr int OP2_BYTES = BK2 * T2 * 2;        // 16 KiB
+constexpr int STAGE2_BYTES = 2 * OP2_BYTES;    // 32 KiB
+constexpr int XTX2_LDS = NST2 * STAGE2_BYTES;  // 128 KiB
+
+__device__ __forceinline__ void stage_operand2(const unsigned short *__restrict__ x, int64_t ld, int64_t tok0, int col0,
+                                               char *lds_op, int wave, int lane)
+{
+    // 16 wave-instructions of 1 KiB (= 2 token rows of 512 bytes), 2 per wave
+    const int s = lane & 31;   // 16-byte slot in the row
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ii = wave * 2 + it;
+        const int k = ii * 2 + (lane >> 5);
+        const int chunk = (s >> 1) ^ (2 * (k & 3));
+        const unsigned short *src = x + (tok0 + k) * ld + col0 + chunk * 16 + (s & 1) * 8;
+        __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_op + ii * 1024), 16, 0, 0);
+    }
+}
+
+struct Frags2 {
+    s16x4 a[4][2], b[2][2];
+};
+
+template <int BASE>
+__device__ __forceinline__ void read_step2(Frags2 &f, const unsigned (&addrA)[4], const unsigned (&addrB)[2])
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        tr_read<BASE>(f.a[u][0], addrA[u]);
+        tr_read<BASE + 4 * 512>(f.a[u][1], addrA[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        tr_read<BASE + OP2_BYTES>(f.b[u][0], addrB[u]);
+        tr_read<BASE + OP2_BYTES + 4 * 512>(f.b[u][1], addrB[u]);
+    }
+}
+
+template <int DTYPE>
+__device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f)
+{
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const s16x8 fa = __builtin_shufflevector(f.a[a][0], f.a[a][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const s16x8 fb = __builtin_shufflevector(f.b[b][0], f.b[b][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[a][b] = mfma16<DTYPE>(fa, fb, acc[a][b]);
+        }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
+                                                     int hidden, int n_ktiles, const uint32_t *__restrict__ tile_table,
+                                                     int n_blocks, int mirror)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int bid;
+    {
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7;
+        const int q = n_blocks >> 3, r = n_blocks & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const uint32_t packed_tile = tile_table[bid];
+    const int ti = (int)(packed_tile >> 16), tj = (int)(packed_tile & 0xffffu);
+    const int m0 = ti * T2, n0 = tj * T2;
+    const int64_t ld = hidden;
+
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int g1 = g & 1, kh = g >> 1;
+    const unsigned lds_base = (unsigned)(uintptr_t)GQ_LDS_PTR(char, smem);
+    unsigned addrA[4], addrB[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ca = ((wr * 4 + u) * 2 + g1) ^ (2 * q4);
+        addrA[u] = lds_base + (8 * kh + q4) * 512 + ca * 32 + p4 * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int cb = ((wc * 2 + u) * 2 + g1) ^ (2 * q4);
+        addrB[u] = lds_base + (8 * kh + q4) * 512 + cb * 32 + p4 * 8;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    auto issue = [&](int kt, char *buf) {
+        stage_operand2(x, ld, (int64_t)kt * BK2, m0, buf, wave, lane);
+        stage_operand2(x, ld, (int64_t)kt * BK2, n0, buf + OP2_BYTES, wave, lane);
+    };
+#pragma unroll
+    for (int st = 0; st < NST2 - 1; ++st)
+        if (st < n_ktiles) issue(st, smem + st * STAGE2_BYTES);
+
+    auto step = [&](auto cur_c, int kt) {
+        constexpr int cur = decltype(cur_c)::value;
+        constexpr int SB = cur * STAGE2_BYTES;
+        // 4 DMA instructions per wave per step; steps kt+1, kt+2 may stay in flight
+        if (n_ktiles - 1 - kt >= NST2 - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST2 - 1 < n_ktiles) issue(kt + NST2 - 1, smem + ((cur + NST2 - 1) % NST2) * STAGE2_BYTES);
+        unsigned sA[4], sB[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sA[u] = addrA[u] + SB;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sB[u] = addrB[u] + SB;
+        Frags2 f0, f1;
+        read_step2<0>(f0, sA, sB);
+        read_step2<16 * 512>(f1, sA, sB);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step2<DTYPE>(acc, f0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step2<DTYPE>(acc, f1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + NST2 <= n_ktiles; kt += NST2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+        step(std::integral_constant<int, 2>{}, kt + 2);
+        step(std::integral_constant<int, 3>{}, kt + 3);
+    }
+    if (kt < n_ktiles) step(std::integral_constant<int, 0>{}, kt++);
+    if (kt < n_ktiles) step(std::integral_constant<int, 1>{}, kt++);
+    if (kt < n_ktiles) step(std::integral_constant<int, 2>{}, kt++);
+
+    const bool do_mirror = mirror && (ti != tj);
+    const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wr * 4 + a) * 32 + (e & 3) + 8 * (e >> 2) + lrow;
                 const int col = n0 + (wc * 2 + b) * 32 + lcol;
                 float *p = hess + (int64_t)row * ld + col;
                 const float v = *p + acc[a][b][e];
@@ -280,21 +485,133 @@ __global__ __launch_bounds__(256) void xtx_generic_kernel(float *__restrict__ he
         }
 }
 
+// Tile order: the (lower triangle of the) nt x nt tile grid cut into SUPER x SUPER super-tiles,
+// super-tiles row-major, tiles row-major inside each.  Entry = (tile_row << 16) | tile_col.
+constexpr int SUPER_TILE = 12;
+
+struct TileTable {
+    int device, nt, lower, n_blocks;
+    uint32_t *dev;
+};
+
+int get_tile_table(int nt, int lower, const uint32_t **out, int *n_blocks_out)
+{
+    static std::mutex mu;
+    static std::vector<TileTable> cache;
+    int device = 0;
+    GQ_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const TileTable &t : cache)
+        if (t.device == device && t.nt == nt && t.lower == lower) {
+            *out = t.dev;
+            *n_blocks_out = t.n_blocks;
+            return GQ_OK;
+        }
+    std::vector<uint32_t> host;
+    const int ns = (nt + SUPER_TILE - 1) / SUPER_TILE;
+    for (int si = 0; si < ns; ++si)
+        for (int sj = 0; sj < (lower ? si + 1 : ns); ++sj)
+            for (int ti = si * SUPER_TILE; ti < std::min(nt, (si + 1) * SUPER_TILE); ++ti)
+                for (int tj = sj * SUPER_TILE; tj < std::min(nt, (sj + 1) * SUPER_TILE); ++tj)
+                    if (!lower || tj <= ti) host.push_back(((uint32_t)ti << 16) | (uint32_t)tj);
+    TileTable t{device, nt, lower, (int)host.size(), nullptr};
+    GQ_HIP(hipMalloc((void **)&t.dev, host.size() * sizeof(uint32_t)));
+    GQ_HIP(hipMemcpy(t.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    cache.push_back(t);
+    *out = t.dev;
+    *n_blocks_out = t.n_blocks;
+    return GQ_OK;
+}
+
+template <int DTYPE, int BKT, int NST>
+int launch_mfma(float *hess, const unsigned short *x, int64_t n_tokens, int64_t hidden, int compute_lower_only,
+                int mirror, hipStream_t stream, int64_t &done)
+{
+    constexpr int LDS = NST * 2 * BKT * TM * 2;
+    const int nt = (int)(hidden / TM);
+    const int n_ktiles = (int)(n_tokens / BKT);
+    const uint32_t *table = nullptr;
+    int n_blocks = 0;
+    int rc = get_tile_table(nt, compute_lower_only, &table, &n_blocks);
+    if (rc) return rc;
+    GQ_HIP(hipFuncSetAttribute((const void *)xtx_mfma_kernel<DTYPE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    hipLaunchKernelGGL((xtx_mfma_kernel<DTYPE, BKT, NST>), dim3(n_blocks), dim3(256), LDS, stream, hess, x, (int)hidden,
+                       n_ktiles, table, n_blocks, mirror);
+    GQ_LAUNCH_CHECK();
+    done = (int64_t)n_ktiles * BKT;
+    return GQ_OK;
+}
+
+template <int DTYPE>
+int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64_t hidden, int compute_lower_only,
+                   int mirror, hipStream_t stream, int64_t &done)
+{
+    const int nt = (int)(hidden / T2);
+    const int n_ktiles = (int)(n_tokens / BK2);
+    const uint32_t *table = nullptr;
+    int n_blocks = 0;
+    int rc = get_tile_table(nt, compute_lower_only, &table, &n_blocks);
+    if (rc) return rc;
+    GQ_HIP(hipFuncSetAttribute((const void *)xtx256_kernel<DTYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
+    hipLaunchKernelGGL(xtx256_kernel<DTYPE>, dim3(n_blocks), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles,
+                       table, n_blocks, mirror);
+    GQ_LAUNCH_CHECK();
+    done = (int64_t)n_ktiles * BK2;
+    return GQ_OK;
+}
+
+// experiment knob: GQ_XTX_VARIANT = "<tokens per step>x<stages>" (128-tiles) or "256"; unset = by shape
+int xtx_variant()
+{
+    static int v = -1;
+    if (v == -1) {
+        const char *e = getenv("GQ_XTX_VARIANT");
+        v = -2;   // -2: not forced, choose by shape
+        if (e) {
+            if (!strcmp(e, "64x2")) v = 0;
+            else if (!strcmp(e, "32x4")) v = 1;
+            else if (!strcmp(e, "32x3")) v = 2;
+            else if (!strcmp(e, "64x3")) v = 3;
+            else if (!strcmp(e, "32x2")) v = 4;
+            else if (!strcmp(e, "256")) v = 5;
+        }
+    }
+    return v;
+}
+
 template <int DTYPE>
 int launch_xtx(float *hess, const unsigned short *x, int64_t n_tokens, int64_t hidden, int save_lower_only,
                int compute_lower_only, hipStream_t stream)
 {
     const int mirror = compute_lower_only && !save_lower_only;
     int64_t done = 0;
-    if (hidden % TM == 0 && n_tokens >= BK) {
-        const int nt = (int)(hidden / TM);
-        const int n_ktiles = (int)(n_tokens / BK);
-        const int n_blocks = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
-        GQ_HIP(hipFuncSetAttribute((const void *)xtx_mfma_kernel<DTYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, XTX_LDS));
-        hipLaunchKernelGGL(xtx_mfma_kernel<DTYPE>, dim3(n_blocks), dim3(256), XTX_LDS, stream, hess, x, (int)hidden,
-                           n_ktiles, nt, n_blocks, compute_lower_only, mirror);
-        GQ_LAUNCH_CHECK();
-        done = (int64_t)n_ktiles * BK;
+    if (hidden % TM == 0 && n_tokens >= 64) {
+        int rc;
+        int variant = xtx_variant();
+        if (variant < 0) {
+            // 256 x 256 tiles (one per CU) when they fill whole rounds of the 256 CUs well enough,
+            // else 128 x 128 tiles at three workgroups per CU
+            variant = 4;
+            if (hidden % T2 == 0) {
+                const int64_t nt2 = hidden / T2, tiles = compute_lower_only ? nt2 * (nt2 + 1) / 2 : nt2 * nt2;
+                const int64_t rounds = gq_cdiv(tiles, 256);
+                if (tiles >= 512 && tiles * 5 >= rounds * 256 * 4) variant = 5;
+            }
+        }
+        switch (variant) {
+        case 0: rc = launch_mfma<DTYPE, 64, 2>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
+        case 1: rc = launch_mfma<DTYPE, 32, 4>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
+        case 2: rc = launch_mfma<DTYPE, 32, 3>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
+        case 3: rc = launch_mfma<DTYPE, 64, 3>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
+        case 5:
+            if (hidden % T2 == 0) {
+                rc = launch_mfma256<DTYPE>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done);
+                break;
+            }
+            [[fallthrough]];
+        default: rc = launch_mfma<DTYPE, 32, 2>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
+        }
+        if (rc) return rc;
     }
     if (done < n_tokens) {
         const int nt = (int)gq_cdiv(hidden, 64);
