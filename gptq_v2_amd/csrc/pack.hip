@@ -14,10 +14,15 @@ __global__ void pack_kernel(const uint8_t *__restrict__ values, int64_t rows, in
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * words_per_row) return;
-    const int64_t row = i / words_per_row, wi = i - row * words_per_row;
+    int64_t row = i / words_per_row, wi = i - row * words_per_row;
+    if (layout == GQ_PACK_W4_KBLOCK) {   // output word i = ((kb * rows) + row) * 8 + w
+        const int64_t kb = i / (rows * 8), rem = i - kb * rows * 8;
+        row = rem >> 3;
+        wi = kb * 8 + (rem & 7);
+    }
     const uint8_t *src = values + row * n;
     uint32_t word = 0;
-    if (layout == GQ_PACK_W4_PAIRS) {
+    if (layout != GQ_PACK_STREAM) {
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int64_t idx = wi * 8 + v;
@@ -47,6 +52,9 @@ __global__ void unpack_kernel(const uint32_t *__restrict__ packed, int64_t rows,
     uint32_t val;
     if (layout == GQ_PACK_W4_PAIRS) {
         val = (src[idx >> 3] >> (4 * w4_pairs_nibble((int)(idx & 7)))) & 15u;
+    } else if (layout == GQ_PACK_W4_KBLOCK) {
+        const uint32_t word = packed[((idx >> 6) * rows + row) * 8 + ((idx & 63) >> 3)];
+        val = (word >> (4 * w4_pairs_nibble((int)(idx & 7)))) & 15u;
     } else {
         const int64_t bit = idx * bits, wi = bit >> 5;
         const int sh = (int)(bit & 31);
@@ -112,7 +120,9 @@ extern "C" int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int 
     GQ_REQUIRE(values && packed, "gq_pack_rows: NULL pointer");
     GQ_REQUIRE(rows >= 0 && n >= 0, "gq_pack_rows: bad shape");
     GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_pack_rows: bit width %d not in {2,3,4,8}", bits);
-    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4), "gq_pack_rows: bad layout %d for %d bits", layout, bits);
+    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4) ||
+                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0),
+               "gq_pack_rows: bad layout %d for %d bits, n = %lld", layout, bits, (long long)n);
     const int64_t wpr = gq_cdiv(n * bits, 32);
     if (rows * wpr == 0) return GQ_OK;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)gq_cdiv(rows * wpr, 256)), dim3(256), 0, (hipStream_t)stream, values, rows, n, bits, layout, wpr, packed);
@@ -126,7 +136,9 @@ extern "C" int gq_unpack_rows(const uint32_t *packed, int64_t rows, int64_t n, i
     GQ_REQUIRE(values && packed, "gq_unpack_rows: NULL pointer");
     GQ_REQUIRE(rows >= 0 && n >= 0, "gq_unpack_rows: bad shape");
     GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_unpack_rows: bit width %d not in {2,3,4,8}", bits);
-    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4), "gq_unpack_rows: bad layout %d for %d bits", layout, bits);
+    GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4) ||
+                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0),
+               "gq_unpack_rows: bad layout %d for %d bits, n = %lld", layout, bits, (long long)n);
     const int64_t wpr = gq_cdiv(n * bits, 32);
     if (rows * n == 0) return GQ_OK;
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)gq_cdiv(rows * n, 256)), dim3(256), 0, (hipStream_t)stream, packed, rows, n, bits, layout, wpr, values);

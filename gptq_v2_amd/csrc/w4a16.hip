@@ -53,17 +53,56 @@ struct WRegs {
     unsigned z_raw;   // zero point (0..255) as loaded; converted where it is used, not where it is
 };                    // loaded, so that the load's latency is not waited for early
 
-__device__ __forceinline__ void load_w(WRegs &w, const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
-                                       const uint8_t *__restrict__ zero, int64_t r_total, int64_t words_per_row,
-                                       int n_groups, int group_size, int64_t n0, int64_t k0, int tid)
+// Packed operand layout (GQ_PACK_W4_KBLOCK): qw[C/64][R][8 words] -- the 64 values of one row's
+// k-step are 32 contiguous bytes and the rows of a k-step follow each other, so the 128 or 256 rows
+// of a tile are one contiguous 4 or 8 KiB piece per k-step; scale and zero are [G][R], so a group's
+// entries for the rows of a tile are contiguous too.
+//
+// Per-thread read position: the 32 values (half a k-step) of one W row, and the scale / zero point
+// of the group they belong to (a group is a multiple of 32 values, so the 32 values never straddle
+// two groups).  Advancing by one k-step is a few adds and compares; no division in the main loop.
+struct WCursor {
+    const uint32_t *q;
+    const unsigned short *s;
+    const uint8_t *z;
+    int rem;          // offset of the thread's 32 values inside their group
+    int group_size;
+    int64_t r_total;
+};
+
+__device__ __forceinline__ WCursor w_cursor(const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
+                                            const uint8_t *__restrict__ zero, int64_t r_total, int group_size, int64_t n0,
+                                            int tid)
 {
     int64_t n = n0 + (tid >> 1);
-    n = n < r_total ? n : r_total - 1;
+    n = n < r_total ? n : r_total - 1;   // rows past the end shadow the last row; never stored
     const int half = tid & 1;
-    w.q = *reinterpret_cast<const u32x4 *>(qw + n * words_per_row + k0 / 8 + half * 4);
-    const int g = (int)((k0 + half * 32) / group_size);
-    w.s_raw = scale[n * n_groups + g];
-    w.z_raw = zero[n * n_groups + g];
+    WCursor c;
+    c.q = qw + n * 8 + half * 4;
+    const int g = (half * 32) / group_size;   // 0, or 1 when the group is 32 wide
+    c.s = scale + g * r_total + n;
+    c.z = zero + g * r_total + n;
+    c.rem = half * 32 - g * group_size;
+    c.group_size = group_size;
+    c.r_total = r_total;
+    return c;
+}
+
+// loads the thread's share of the current k-step and moves the cursor to the next one
+__device__ __forceinline__ void load_w(WRegs &w, WCursor &c)
+{
+    w.q = *reinterpret_cast<const u32x4 *>(c.q);
+    w.s_raw = *c.s;
+    w.z_raw = *c.z;
+    c.q += c.r_total * 8;
+    c.rem += WK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)   // WK = 64 <= 2 * group_size
+        if (c.rem >= c.group_size) {
+            c.rem -= c.group_size;
+            c.s += c.r_total;
+            c.z += c.r_total;
+        }
 }
 
 __device__ __forceinline__ void w_scale_zero(const WRegs &w, f16x2 &s2, f16x2 &z2)
@@ -135,8 +174,6 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int64_t m0 = (int64_t)(bid / tiles_n) * WT, n0 = (int64_t)(bid % tiles_n) * WT;
-    const int64_t words_per_row = c_total / 8;
-    const int n_groups = (int)(c_total / group_size);
     const int n_ktiles = (int)(c_total / WK);
 
     const int wr = wave >> 1, wc = wave & 1;
@@ -163,8 +200,9 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
     WRegs wregs;
+    WCursor wcsr = w_cursor(qw, scale, zero, r_total, group_size, n0, tid);
     stage_x(x, c_total, m_total, m0, 0, smem, wave, lane);
-    load_w(wregs, qw, scale, zero, r_total, words_per_row, n_groups, group_size, n0, 0, tid);
+    load_w(wregs, wcsr);
     store_w(wregs, smem + W_OP_BYTES, tid);
 
     auto step = [&](auto cur_c, int kt) {
@@ -174,7 +212,7 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
         const bool more = kt + 1 < n_ktiles;
         if (more) {
             stage_x(x, c_total, m_total, m0, (int64_t)(kt + 1) * WK, smem + (cur ^ 1) * W_STAGE_BYTES, wave, lane);
-            load_w(wregs, qw, scale, zero, r_total, words_per_row, n_groups, group_size, n0, (int64_t)(kt + 1) * WK, tid);
+            load_w(wregs, wcsr);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -222,18 +260,104 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
 // two LDS stages of 64 KiB (x image 32 KiB + W image 32 KiB), one workgroup per CU.  Same images,
 // swizzle and dequantisation as above; every thread expands the 32 nibbles of half a W row.
 // The two waves of each SIMD run half a k-step apart (see the main loop).
+// ---- helpers of the 256 x 256 kernel -----------------------------------------------------------
+// Expansion constants of one thread's 32 values (one group): the two exponent-trick biases with
+// the zero point folded in, and the scale, each in both halves of a packed pair.
+struct DeqConst {
+    f16x2 zb0;   // 1024 + z : bias of a nibble sitting in bits 0..3 of a half   (0x6400 | q)
+    f16x2 zb1;   //   64 + z : bias of a nibble sitting in bits 4..7 of a half   (0x5400 | q << 4)
+    f16x2 s2;
+};
+
+__device__ __forceinline__ DeqConst deq_const(const WRegs &w)
+{
+    DeqConst d;
+    const _Float16 s = __builtin_bit_cast(_Float16, (unsigned short)w.s_raw);
+    const _Float16 zb = (_Float16)(1024.0f + (float)w.z_raw);   // exact: <= 1279
+    d.s2 = f16x2{s, s};
+    d.zb0 = f16x2{zb, zb};
+    d.zb1 = d.zb0 - f16x2{(_Float16)960.0f, (_Float16)960.0f};  // exact
+    return d;
+}
+
+// (x & mask) | magic in one instruction; the mask rides in an SGPR (one literal per VOP3 at most)
+__device__ __forceinline__ unsigned and_or_b32(unsigned x, unsigned mask, unsigned magic)
+{
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask), "v"(magic));
+    return r;
+}
+
+// The 8 values of one packed word as 4 fp16 pairs (q - z) * s, exactly as the reference's
+// dequantisation rounds them: nibbles in bits 0..3 of a half become 1024 + q, nibbles in bits 4..7
+// become 64 + q without a shift, the upper byte of each half is handled the same way after one
+// shift by 8.  13 VALU instructions per word.
+__device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConst &d, unsigned magic0, unsigned magic1)
+{
+    const unsigned hi = word >> 8;
+    f16x2 v0 = __builtin_bit_cast(f16x2, and_or_b32(word, 0x000F000Fu, magic0)) - d.zb0;
+    f16x2 v1 = __builtin_bit_cast(f16x2, and_or_b32(word, 0x00F000F0u, magic1)) - d.zb1;
+    f16x2 v2 = __builtin_bit_cast(f16x2, and_or_b32(hi, 0x000F000Fu, magic0)) - d.zb0;
+    f16x2 v3 = __builtin_bit_cast(f16x2, and_or_b32(hi, 0x00F000F0u, magic1)) - d.zb1;
+    u32x4 out;
+    out[0] = __builtin_bit_cast(unsigned, v0 * d.s2);
+    out[1] = __builtin_bit_cast(unsigned, v1 * d.s2);
+    out[2] = __builtin_bit_cast(unsigned, v2 * d.s2);
+    out[3] = __builtin_bit_cast(unsigned, v3 * d.s2);
+    return out;
+}
+
+// Wave-uniform read position of the 256-row tile in the packed weights (group sizes that are
+// multiples of the 64-deep k-step: all 64 values of a row's k-step share one group).  Lives in
+// SGPRs; each thread adds its own constant offsets.
+struct W2Cursor {
+    const char *q;             // packed words of the tile's first row at the current k-step
+    const unsigned short *s;   // scale of the tile's first row, current group
+    const uint8_t *z;
+    int rem;                   // k offset inside the current group
+};
+
+#ifdef GQ_W4_NO_PRIO
+#define GQ_PRIO(p)
+#else
+#define GQ_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+#ifdef GQ_W4_TRACE
+// Debug build only (tools/trace_w4.py): per-wave cycle stamps of the last steady-state k-step.
+__device__ unsigned long long *g_w4_trace = nullptr;
+#define GQ_TR(i) if constexpr (MORE2) ts[i] = __builtin_readcyclecounter()
+#else
+#define GQ_TR(i)
+#endif
 constexpr int W2T = 256;
 constexpr int W2_OP_BYTES = W2T * WK * 2;        // 32 KiB
 constexpr int W2_STAGE_BYTES = 2 * W2_OP_BYTES;  // 64 KiB
 constexpr int W2_LDS = 2 * W2_STAGE_BYTES;       // 128 KiB
 
-__device__ __forceinline__ void stage_x2(const unsigned short *__restrict__ x, int64_t ld, int64_t m_total, int64_t m0,
-                                         int64_t k0, char *lds_a, int wave, int lane)
+// x tile (256 rows x 64 halves) by LDS-DMA: 32 wave-instructions of 1 KiB (8 rows each), issued by
+// `n_waves` waves (`w` = index of this wave among them).
+// one of the 32 wave-instructions of the x tile (ii = 0..31)
+__device__ __forceinline__ void stage_x2_one(const unsigned short *__restrict__ x, int64_t ld, int64_t m_total, int64_t m0,
+                                             int64_t k0, char *lds_a, int ii, int lane)
 {
     const int rloc = lane >> 3, s = lane & 7;
+    const int row = ii * 8 + rloc;
+    const int chunk = s ^ ((row >> 1) & 7);
+    int64_t m = m0 + row;
+    m = m < m_total ? m : m_total - 1;
+    const unsigned short *src = x + m * ld + k0 + chunk * 8;
+    __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_a + ii * 1024), 16, 0, 0);
+}
+
+template <int N_WAVES>
+__device__ __forceinline__ void stage_x2(const unsigned short *__restrict__ x, int64_t ld, int64_t m_total, int64_t m0,
+                                         int64_t k0, char *lds_a, int w, int lane)
+{
+    const int rloc = lane >> 3, s = lane & 7;
+    constexpr int PER_WAVE = 32 / N_WAVES;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int ii = wave * 4 + it;       // 32 wave-instructions of 8 rows
+    for (int it = 0; it < PER_WAVE; ++it) {
+        const int ii = w * PER_WAVE + it;
         const int row = ii * 8 + rloc;
         const int chunk = s ^ ((row >> 1) & 7);
         int64_t m = m0 + row;
@@ -249,6 +373,9 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
                                                         int64_t c_total, int group_size, int tiles_n, int n_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef GQ_W4_TRACE
+    const unsigned long long tk0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -259,8 +386,6 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int64_t m0 = (int64_t)(bid / tiles_n) * W2T, n0 = (int64_t)(bid % tiles_n) * W2T;
-    const int64_t words_per_row = c_total / 8;
-    const int n_groups = (int)(c_total / group_size);
     const int n_ktiles = (int)(c_total / WK);
 
     const int wr = wave >> 2, wc = wave & 3;
@@ -295,15 +420,61 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     // vmcnt for this wave's DMA) before the barrier that ends it, so the barrier hands the data over.
     // W registers run two steps ahead: the packed words of step k+1 are in registers when step k
     // starts (loaded during step k-1).
-    WRegs wcur, wnext;
-    stage_x2(x, c_total, m_total, m0, 0, smem, wave, lane);
-    load_w(wcur, qw, scale, zero, r_total, words_per_row, n_groups, group_size, n0, 0, tid);
-    store_w(wcur, smem + W2_OP_BYTES, tid);
-    if (n_ktiles > 1) load_w(wcur, qw, scale, zero, r_total, words_per_row, n_groups, group_size, n0, WK, tid);
-    __syncthreads();
+    WRegs wcur, wnext{};
+    W2Cursor csr;
+    csr.q = reinterpret_cast<const char *>(qw + n0 * 8);
+    csr.s = scale + n0;
+    csr.z = zero + n0;
+    csr.rem = 0;
+    unsigned voff_q, voff_g;   // this thread's row (clamped to the last one) and half inside the tile
+    {
+        int64_t nl = tid >> 1;
+        nl = n0 + nl < r_total ? nl : r_total - 1 - n0;   // rows past the end shadow the last row; never stored
+        voff_q = (unsigned)(nl * 32 + (tid & 1) * 16);
+        voff_g = (unsigned)nl;
+    }
+    const int64_t kstep_bytes = r_total * 32;
+    auto load_w2 = [&](WRegs &w) {
+        // Issued as asm so that hipcc neither widens the 16- and 8-bit results right behind the loads
+        // (which drags a vmcnt(0) to the next barrier) nor counts them: the consumer waits by hand.
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.q) : "v"(csr.q + voff_q) : "memory");
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(w.s_raw) : "v"(csr.s + voff_g) : "memory");
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(w.z_raw) : "v"(csr.z + voff_g) : "memory");
+        csr.q += kstep_bytes;
+        csr.rem += WK;
+        if (csr.rem >= group_size) {   // group_size is a multiple of WK here
+            csr.rem = 0;
+            csr.s += r_total;
+            csr.z += r_total;
+        }
+    };
+    unsigned magic0 = 0x64006400u, magic1 = 0x54005400u;
+    asm volatile("" : "+v"(magic0), "+v"(magic1));   // keep them in VGPRs (operands of v_and_or_b32)
+    const int wrow = tid >> 1, whalf = tid & 1;
+    auto store_part = [&](const WRegs &w, const DeqConst &d, int wi, char *lds_b) {
+        const u32x4 out = expand_word(w.q[wi], d, magic0, magic1);
+        const int chunk = (whalf * 4 + wi) ^ ((wrow >> 1) & 7);
+        *reinterpret_cast<u32x4 *>(lds_b + wrow * 128 + chunk * 16) = out;
+    };
     const bool late = wave >= 4;   // wave-uniform (readfirstlane above)
+    stage_x2<8>(x, c_total, m_total, m0, 0, smem, wave, lane);
+    load_w2(wcur);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcur.q), "+v"(wcur.s_raw), "+v"(wcur.z_raw)::"memory");
+    {
+        const DeqConst d = deq_const(wcur);
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) store_part(wcur, d, wi, smem + W2_OP_BYTES);
+    }
+    if (n_ktiles > 1) load_w2(wcur);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcur.q), "+v"(wcur.s_raw), "+v"(wcur.z_raw)::"memory");
+    __syncthreads();
+    // x tile of step 1: waited for (vmcnt(0)) by every wave before the last barrier of step 0
+    if (n_ktiles > 1) stage_x2<8>(x, c_total, m_total, m0, WK, smem + W2_STAGE_BYTES, wave, lane);
     if (late) __builtin_amdgcn_s_barrier();
 
+#ifdef GQ_W4_TRACE
+    unsigned long long ts[13] = {};
+#endif
     u32x4 fa[2][4], fb[2][2];
     auto read_frags = [&](int slot, unsigned sb, int kk) {
 #pragma unroll
@@ -311,13 +482,21 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
 #pragma unroll
         for (int u = 0; u < 2; ++u) lds_read_b128<0>(fb[slot][u], rowB[u] + sb + choff[kk]);
     };
-    auto mfmas = [&](int slot) {
+    // 8 MFMAs of one 16-deep k-chunk; `between(i)` runs after the MFMAs 1 and 5 of the chunk (one
+    // global load per four MFMAs keeps the address unit far from saturation while the pipe is busy)
+    auto mfmas = [&](int slot, auto between) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[slot][a]),
                                                                    __builtin_bit_cast(f16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
+                if (b == 1 && (a == 0 || a == 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    between(a >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     };
     auto seg_barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -327,69 +506,154 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // MORE: a next step exists (stage its x tile, expand its W tile from `wuse`);
-    // MORE2: a step after that exists (fetch its packed W words into `wload`).
-    // The steady-state loop runs with both flags constant, so hipcc's own load counting stays exact
-    // (no branches between a load and its use).
-    auto body = [&](auto more_c, auto more2_c, int kt, WRegs &wuse, WRegs &wload) {
+    // MORE: a next step exists (expand its W tile from `wuse`);
+    // MORE2: a step after that exists (fetch its packed W words and its x tile).
+    //
+    // Global loads are issued from inside the MFMA segments, one between every four MFMAs: there
+    // the issuing wave only waits for the matrix pipe, so the issue costs nothing, and the loads
+    // are spread evenly over time.  Issued at the head of a read segment they delay the LDS reads
+    // and the expansion behind them by several hundred cycles; issued in a burst after the MFMAs
+    // they hold up the barrier the partner is waiting at.
+    //   x tile of step k+2 (it replaces the tile of step k in LDS, so every read of step k -- the
+    //   R2 of both halves -- must lie before a barrier the issuing wave has passed):
+    //     waves 4..7 issue rows 0..127 from their M2 of step k   (wait: end of their R2 of step k+1)
+    //     waves 0..3 issue rows 128..255 from their M1 of step k+1 (wait: end of their M2 of step k+1)
+    //   packed W words / scale / zero of step k+2: every wave, at the end of its M1 of step k,
+    //   consumed (moved to `wuse`) at the end of its M2 of step k.
+    // All of these loads are invisible to hipcc's wait insertion (DMA has no register result, the W
+    // loads are asm), so every vmcnt below is counted by hand in program order per wave half:
+    //   waves 0..3:  M1(k): [4 DMA step k+1 -> if k > 0] 3 W   | M2(k) end: vmcnt(0)
+    //   waves 4..7:  M1(k): 3 W | M2(k): 4 DMA, then vmcnt(4) for the W words | R2(k+1) end: vmcnt(3)
+    //                (the 3 W loads of M1(k+1) are younger than the DMA)
+    auto body = [&](auto more_c, auto more2_c, auto first_c, int kt, WRegs &wuse, WRegs &wload) {
         constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;   // step 0: its successor's x tile was staged in the prologue
         const unsigned sb = (unsigned)(kt & 1) * W2_STAGE_BYTES;
+        char *cur = smem + (kt & 1) * W2_STAGE_BYTES;
         char *nxt = smem + ((kt + 1) & 1) * W2_STAGE_BYTES;
         char *nb = nxt + W2_OP_BYTES;
+        auto nothing = [](int) {};
         // ---- R1
-        // Use `wuse` once BEFORE any DMA is issued: with an LDS-DMA in flight hipcc waits vmcnt(0)
-        // at the first use of an ordinary load's result, which here would drain the DMA just issued;
-        // at this point only the (old) loads of `wuse` itself can be outstanding.
-        if constexpr (MORE) asm volatile("" ::"v"(wuse.q), "v"(wuse.s_raw), "v"(wuse.z_raw));
-        if constexpr (MORE) stage_x2(x, c_total, m_total, m0, (int64_t)(kt + 1) * WK, nxt, wave, lane);
-        if constexpr (MORE2)
-            load_w(wload, qw, scale, zero, r_total, words_per_row, n_groups, group_size, n0, (int64_t)(kt + 2) * WK, tid);
+        GQ_TR(0);
         read_frags(0, sb, 0);
         read_frags(1, sb, 1);
+        GQ_TR(10);
+        __builtin_amdgcn_sched_barrier(0);   // reads first: their latency runs under the expansion
+        DeqConst dq;
         if constexpr (MORE) {
-            store_w_part<0>(wuse, nb, tid);
-            store_w_part<1>(wuse, nb, tid);
+            dq = deq_const(wuse);
+            store_part(wuse, dq, 0, nb);
+            store_part(wuse, dq, 1, nb);
         }
+        GQ_TR(11);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GQ_TR(1);
         seg_barrier();
         // ---- M1
-        __builtin_amdgcn_s_setprio(1);
-        mfmas(0);
-        mfmas(1);
-        __builtin_amdgcn_s_setprio(0);
+        GQ_TR(2);
+        GQ_PRIO(1);
+        if constexpr (MORE && !FIRST) {
+            // waves 0..3: lower half of the x tile of step kt+1
+            auto dma_lo = [&](int i) {
+                if (!late) stage_x2_one(x, c_total, m_total, m0, (int64_t)(kt + 1) * WK, nxt, 16 + wave * 4 + i, lane);
+            };
+            auto dma_hi = [&](int i) {
+                if (!late) stage_x2_one(x, c_total, m_total, m0, (int64_t)(kt + 1) * WK, nxt, 16 + wave * 4 + 2 + i, lane);
+            };
+            mfmas(0, dma_lo);
+            mfmas(1, dma_hi);
+        } else {
+            mfmas(0, nothing);
+            mfmas(1, nothing);
+        }
+        GQ_PRIO(0);
+        GQ_TR(12);
+        if constexpr (MORE2) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_w2(wload);
+        }
+        GQ_TR(3);
         seg_barrier();
         // ---- R2
+        GQ_TR(4);
         read_frags(0, sb, 2);
         read_frags(1, sb, 3);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) {
-            store_w_part<2>(wuse, nb, tid);
-            store_w_part<3>(wuse, nb, tid);
+            store_part(wuse, dq, 2, nb);
+            store_part(wuse, dq, 3, nb);
         }
-        // this wave's DMA of the next x tile must have landed before the barrier that frees it for
-        // reading; the 3 younger loads (W words, scale, zero of step k+2) may stay in flight
-        if constexpr (MORE2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // waves 4..7: their half of the next x tile (DMA from the previous M2; from the prologue in
+        // step 0) must have landed before this barrier; the 3 younger W loads of M1 may stay in flight
+        if constexpr (MORE) {
+            if (late) {
+                if constexpr (MORE2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GQ_TR(5);
         seg_barrier();
         // ---- M2
-        __builtin_amdgcn_s_setprio(1);
-        mfmas(0);
-        mfmas(1);
-        __builtin_amdgcn_s_setprio(0);
+        GQ_TR(6);
+        GQ_PRIO(1);
+        if constexpr (MORE2) {
+            // waves 4..7: upper half of the x tile of step kt+2
+            auto dma_lo = [&](int i) {
+                if (late) stage_x2_one(x, c_total, m_total, m0, (int64_t)(kt + 2) * WK, cur, (wave - 4) * 4 + i, lane);
+            };
+            auto dma_hi = [&](int i) {
+                if (late) stage_x2_one(x, c_total, m_total, m0, (int64_t)(kt + 2) * WK, cur, (wave - 4) * 4 + 2 + i, lane);
+            };
+            mfmas(0, dma_lo);
+            mfmas(1, dma_hi);
+        } else {
+            mfmas(0, nothing);
+            mfmas(1, nothing);
+        }
+        GQ_PRIO(0);
+        GQ_TR(7);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE2) {
+            // W words of step kt+2 (loaded at the end of M1) move to `wuse`; waves 0..3 also collect
+            // their DMA of M1 here, waves 4..7 leave the 4 DMA just issued in flight
+            if (late) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wuse = wload;
+            asm volatile("" : "+v"(wuse.q), "+v"(wuse.s_raw), "+v"(wuse.z_raw)::"memory");
+        } else if constexpr (MORE) {
+            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMA of M1 (of the prologue in step 0)
+        }
+        GQ_TR(9);
         seg_barrier();
+        GQ_TR(8);
     };
     using T = std::true_type;
     using F = std::false_type;
+#ifdef GQ_W4_TRACE
+    const unsigned long long tk1 = __builtin_readcyclecounter();
+#endif
     int kt = 0;
-    for (; kt + 2 < n_ktiles; ++kt) {
-        body(T{}, T{}, kt, wcur, wnext);
-        wcur = wnext;   // the loads into wnext are a whole step old here
-    }
-    if (kt + 1 < n_ktiles) {
-        body(T{}, F{}, kt, wcur, wnext);
+    if (n_ktiles > 2) {
+        body(T{}, T{}, T{}, 0, wcur, wnext);
+        for (kt = 1; kt + 2 < n_ktiles; ++kt) body(T{}, T{}, F{}, kt, wcur, wnext);
+        body(T{}, F{}, F{}, kt, wcur, wnext);
         ++kt;
+        body(F{}, F{}, F{}, kt, wcur, wnext);
+    } else if (n_ktiles == 2) {
+        body(T{}, F{}, T{}, 0, wcur, wnext);
+        body(F{}, F{}, F{}, 1, wcur, wnext);
+    } else {
+        body(F{}, F{}, T{}, 0, wcur, wnext);
     }
-    if (kt < n_ktiles) body(F{}, F{}, kt, wcur, wnext);
     if (!late) __builtin_amdgcn_s_barrier();
+#ifdef GQ_W4_TRACE
+    const unsigned long long tk2 = __builtin_readcyclecounter();
+    if (g_w4_trace && blockIdx.x == 8 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) g_w4_trace[wave * 32 + i] = ts[i];
+    }
+#endif
 
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -402,9 +666,25 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
                 if (row < m_total && col < r_total)
                     y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
             }
+#ifdef GQ_W4_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk3 = __builtin_readcyclecounter(), tr3 = __builtin_amdgcn_s_memrealtime();
+    if (g_w4_trace && blockIdx.x == 8 && lane == 0) {
+        unsigned long long *o = g_w4_trace + wave * 32 + 13;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tr0; o[5] = tr3;
+    }
+#endif
 }
 
 }  // namespace
+
+#ifdef GQ_W4_TRACE
+extern "C" int gq_debug_w4_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_w4_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+#endif
 
 extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
                              const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size, gq_stream_t stream)
@@ -416,7 +696,7 @@ extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_pac
                "gq_w4a16_gemm: group size %d must be a multiple of 32 dividing in_features", group_size);
     GQ_REQUIRE((((uintptr_t)x | (uintptr_t)qweight_packed | (uintptr_t)y) & 15) == 0, "gq_w4a16_gemm: pointers must be 16-byte aligned");
     if (m == 0) return GQ_OK;
-    if (m >= W2T && r >= W2T) {
+    if (m >= W2T && r >= W2T && group_size % WK == 0) {
         const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, W2T);
         const int n_blocks = tiles_m * tiles_n;
         GQ_HIP(hipFuncSetAttribute((const void *)w4a16_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));

@@ -14,7 +14,7 @@ from . import _lib
 
 GQ_F16, GQ_BF16 = 0, 1
 SEM_KERNEL, SEM_PYTHON = 0, 1
-PACK_STREAM, PACK_W4_PAIRS = 0, 1
+PACK_STREAM, PACK_W4_PAIRS, PACK_W4_KBLOCK = 0, 1, 2
 
 _DTYPE_CODE = {torch.float16: GQ_F16, torch.bfloat16: GQ_BF16}
 
@@ -211,7 +211,12 @@ def words_per_row(n: int, bits: int) -> int:
 def pack_rows(values: torch.Tensor, bits: int, layout: int = PACK_STREAM) -> torch.Tensor:
     _check(values, "values", torch.uint8, 2)
     rows, n = values.shape
-    out = torch.empty(rows, words_per_row(n, bits), dtype=torch.int32, device=values.device)
+    if layout == PACK_W4_KBLOCK:
+        if bits != 4 or n % 64:
+            raise ValueError("pack_rows: the k-block layout needs 4-bit values and n % 64 == 0")
+        out = torch.empty(n // 64, rows, 8, dtype=torch.int32, device=values.device)
+    else:
+        out = torch.empty(rows, words_per_row(n, bits), dtype=torch.int32, device=values.device)
     with torch.cuda.device(values.device):
         rc = _lib.load().gq_pack_rows(_p(values), rows, n, bits, layout, _p(out), _stream(values))
     _lib.check(rc, "gq_pack_rows")
@@ -219,10 +224,16 @@ def pack_rows(values: torch.Tensor, bits: int, layout: int = PACK_STREAM) -> tor
 
 
 def unpack_rows(packed: torch.Tensor, bits: int, n: int, layout: int = PACK_STREAM) -> torch.Tensor:
-    _check(packed, "packed", torch.int32, 2)
-    rows = packed.shape[0]
-    if packed.shape[1] != words_per_row(n, bits):
-        raise ValueError("unpack_rows: word count does not match n and bits")
+    if layout == PACK_W4_KBLOCK:
+        _check(packed, "packed", torch.int32, 3)
+        rows = packed.shape[1]
+        if bits != 4 or n % 64 or packed.shape[0] != n // 64 or packed.shape[2] != 8:
+            raise ValueError("unpack_rows: k-block layout is (n/64, rows, 8) words of 4-bit values")
+    else:
+        _check(packed, "packed", torch.int32, 2)
+        rows = packed.shape[0]
+        if packed.shape[1] != words_per_row(n, bits):
+            raise ValueError("unpack_rows: word count does not match n and bits")
     out = torch.empty(rows, n, dtype=torch.uint8, device=packed.device)
     with torch.cuda.device(packed.device):
         rc = _lib.load().gq_unpack_rows(_p(packed), rows, n, bits, layout, _p(out), _stream(packed))
@@ -243,16 +254,19 @@ def permute_columns(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale: torch.Tensor, qzero: torch.Tensor,
+def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Tensor, qzero_t: torch.Tensor,
                group_size: int) -> torch.Tensor:
-    """x (M, C) fp16, columns in permuted order -> y (M, R) fp16."""
+    """x (M, C) fp16, columns in permuted order -> y (M, R) fp16.
+    qweight_packed (C/64, R, 8) int32 in the k-block layout, scale_t (G, R) fp16, qzero_t (G, R) uint8."""
     _check(x, "x", torch.float16, 2)
-    _check(qweight_packed, "qweight_packed", torch.int32, 2)
-    _check(scale, "scale", torch.float16, 2)
-    _check(qzero, "qzero", torch.uint8, 2)
+    _check(qweight_packed, "qweight_packed", torch.int32, 3)
+    _check(scale_t, "scale_t", torch.float16, 2)
+    _check(qzero_t, "qzero_t", torch.uint8, 2)
+    scale, qzero = scale_t, qzero_t
     m, c = x.shape
-    r = qweight_packed.shape[0]
-    if qweight_packed.shape[1] * 8 != c or scale.shape != (r, c // group_size) or qzero.shape != scale.shape:
+    r = qweight_packed.shape[1]
+    if (c % 64 or qweight_packed.shape[0] * 64 != c or qweight_packed.shape[2] != 8 or group_size <= 0
+            or c % group_size or scale.shape != (c // group_size, r) or qzero.shape != scale.shape):
         raise ValueError("w4a16_gemm: inconsistent shapes")
     y = torch.empty(m, r, dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):

@@ -139,8 +139,9 @@ class QuantLinear(nn.Module):
     """Packed int4 Linear: ``pack`` takes a ``quant_meta`` dict, ``forward`` runs the
     W4A16 dequant-GEMM (activations gathered into act-order first when the layer has one).
 
-    Packed state: ``qweight`` int32 (R, C/8) in the pair-interleaved nibble order the GEMM reads,
-    ``scales`` fp16 (R, G), ``qzeros`` uint8 (R, G), ``perm`` int32 (C) or None.
+    Packed state, laid out so that a GEMM tile reads contiguous memory: ``qweight`` int32
+    (C/64, R, 8) (pair-interleaved nibbles, k-block major), ``scales`` fp16 (G, R), ``qzeros`` uint8
+    (G, R), ``perm`` int32 (C) or None.
     ``unpack`` returns the original one-value-per-byte ``quant_meta`` tensors bit for bit.
     """
 
@@ -172,9 +173,11 @@ class QuantLinear(nn.Module):
         q = quant_meta["qweight"].to(device=device, dtype=torch.uint8).contiguous()
         if q.shape != (self.out_features, self.in_features):
             raise ValueError("quant_meta does not match this layer's shape")
-        self.qweight = ops.pack_rows(q, self.bits, ops.PACK_W4_PAIRS)
-        self.scales = quant_meta["scale"].to(device=device, dtype=torch.float16).contiguous()
-        self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).contiguous()
+        if self.in_features % 64:
+            raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
+        self.qweight = ops.pack_rows(q, self.bits, ops.PACK_W4_KBLOCK)
+        self.scales = quant_meta["scale"].to(device=device, dtype=torch.float16).t().contiguous()
+        self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
         perm_inv = quant_meta.get("perm_inv")
         if perm_inv is None:
             self.perm = None
@@ -188,7 +191,7 @@ class QuantLinear(nn.Module):
 
     @torch.no_grad()
     def unpack(self) -> dict:
-        q = ops.unpack_rows(self.qweight, self.bits, self.in_features, ops.PACK_W4_PAIRS)
+        q = ops.unpack_rows(self.qweight, self.bits, self.in_features, ops.PACK_W4_KBLOCK)
         c = self.in_features
         if self.perm is None:
             perm_inv = torch.arange(c, dtype=torch.int16, device=q.device)
@@ -197,7 +200,8 @@ class QuantLinear(nn.Module):
             perm_inv[self.perm.long()] = torch.arange(c, device=q.device)
             perm_inv = perm_inv.to(torch.int16)
         g = c // self.group_size
-        return {"qweight": q, "scale": self.scales, "qzero": self.qzeros, "qscale": None, "sscale": None,
+        return {"qweight": q, "scale": self.scales.t().contiguous(), "qzero": self.qzeros.t().contiguous(),
+                "qscale": None, "sscale": None,
                 "perm_inv": perm_inv,
                 "group_sizes": torch.full([g], self.group_size, dtype=torch.int16, device=q.device),
                 "group_bit_widths": torch.full([g], self.bits, dtype=torch.uint8, device=q.device),

@@ -138,7 +138,11 @@ int gq_dequantize(const uint8_t *qweight, const void *scale, const uint8_t *qzer
 #define GQ_PACK_STREAM 0      /* value i at bits [i*bits, i*bits+bits) of the row's bit stream */
 #define GQ_PACK_W4_PAIRS 1    /* 4-bit only: within each uint32, values 0..7 sit in nibbles
                                  0,4,1,5,2,6,3,7, so (w >> 4p) & 0x000F000F yields the value pair
-                                 (2p, 2p+1) in the two 16-bit halves -- the W4A16 GEMM operand */
+                                 (2p, 2p+1) in the two 16-bit halves */
+#define GQ_PACK_W4_KBLOCK 2   /* 4-bit only, n a multiple of 64: words of GQ_PACK_W4_PAIRS stored as
+                                 packed[n/64][rows][8] -- the 64 values of one row's k-step are 32
+                                 contiguous bytes and consecutive rows follow each other, so a GEMM
+                                 tile reads one contiguous piece per k-step: the W4A16 GEMM operand */
 
 /* Packing of rows of `bits`-wide values (2, 3, 4 or 8) into uint32 words,
  * words_per_row = ceil(n*bits/32), rows padded with zero bits.
@@ -153,11 +157,13 @@ int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t
                        gq_stream_t stream);
 
 /* y[M][R] (fp16) = x[M][C] (fp16, columns already in permuted order) * W^T with
- * W[r][k] = half(q[r][k] - z[r][g(k)]) * scale[r][g(k)] taken from 4-bit packed rows
- * (GQ_PACK_W4_PAIRS layout, C/8 words per row), uniform group size, fp32 accumulation.
+ * W[r][k] = half(q[r][k] - z[g(k)][r]) * scale[g(k)][r]: q from 4-bit packed weights in the
+ * GQ_PACK_W4_KBLOCK layout ([C/64][R][8] words), scale_t fp16 [G][R] and qzero_t uint8 [G][R]
+ * (the transposes of the reference's (R, G) tensors), uniform group size (a multiple of 32
+ * dividing C), C a multiple of 64, fp32 accumulation.
  * Fills the slot of the dense fp16 nn.Linear at llama.py:172-177. */
-int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
-                  const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size,
+int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale_t,
+                  const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size,
                   gq_stream_t stream);
 
 #ifdef __cplusplus

@@ -379,6 +379,12 @@ def test_pack_matches_oracle_layout_and_roundtrips(amd, oracle, gpu, bits, n):
         w0 = int(pp[0, 0]) & 0xFFFFFFFF
         pairs = [((w0 >> (4 * k)) & 15, (w0 >> (4 * k + 16)) & 15) for k in range(4)]
         assert [x for pr in pairs for x in pr] == v[0, :8].tolist()
+        if n % 64 == 0:
+            # k-block-major layout of the GEMM operand: the same words, [n/64][rows][8]
+            pk = amd.ops.pack_rows(v.to(gpu), 4, amd.ops.PACK_W4_KBLOCK)
+            assert pk.shape == (n // 64, 7, 8)
+            assert torch.equal(pk.cpu(), pp.cpu().reshape(7, n // 64, 8).permute(1, 0, 2))
+            assert torch.equal(amd.ops.unpack_rows(pk, 4, n, amd.ops.PACK_W4_KBLOCK).cpu(), v)
 
 
 @pytest.mark.parametrize("case", ["64x256_b4", "64x256_b4_noact"])
@@ -424,6 +430,27 @@ def test_w4a16_gemm_llama_shape(amd, gpu):
         ref = x[rows].double() @ w[cols].double().t()
         got = y[rows][:, cols].double()
         assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("m,r,c,gsz", [(300, 200, 256, 32), (512, 520, 384, 64), (256, 256, 192, 96),
+                                        (700, 1000, 1024, 256), (257, 300, 128, 128)])
+def test_w4a16_gemm_group_sizes_and_ragged_tiles(amd, gpu, m, r, c, gsz):
+    """Every group size class (32: two groups per k-step; 96: not a multiple of the k-step; 64..256),
+    row and column counts that do not fill the last tile, both tile sizes; full comparison against
+    the fp64 product with the dequantised weight."""
+    gen = torch.Generator(device=gpu).manual_seed(m + r + c + gsz)
+    q = torch.randint(0, 16, (r, c), generator=gen, device=gpu, dtype=torch.uint8)
+    scale = (torch.rand(r, c // gsz, generator=gen, device=gpu) * 0.01 + 0.002).half()
+    zero = torch.randint(0, 16, (r, c // gsz), generator=gen, device=gpu, dtype=torch.uint8)
+    meta = {"qweight": q, "scale": scale, "qzero": zero, "perm_inv": torch.arange(c, dtype=torch.int16),
+            "group_sizes": torch.full([c // gsz], gsz, dtype=torch.int16), "group_bit_widths": torch.full([c // gsz], 4, dtype=torch.uint8)}
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    assert layer.perm is None
+    w = amd.quant.reconstruct_weight(meta, torch.float16, gpu)
+    x = torch.randn(m, c, generator=gen, device=gpu).half()
+    y = layer(x)
+    ref = x.double() @ w.double().t()
+    assert (y.double() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
 
 
 def test_c_abi_rejects_bad_arguments(amd, gpu):

@@ -1,7 +1,7 @@
 """Micro-benchmark of the XtX kernel (experiment helper, not part of the product)."""
 import os, sys, time, json
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gptq_v2_amd as amd
 dev = torch.device("cuda:0")
 res = {}
