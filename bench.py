@@ -245,7 +245,7 @@ def main():
             "int4_gemm_tflops": round(w4_tflops, 1),
             "int4_gemm_frac_of_f16_mfma_peak": round(w4_tflops / MFMA_F16_PEAK_TFLOPS, 4),
             "breakdown_ms_per_step": breakdown,
-            "roofline": {"kernel": "xtx_mfma_kernel (H += X^T X, C=4096, %d tokens per launch)" % tokens_call,
+            "roofline": {"kernel": "xtx256_kernel (H += X^T X, C=4096, %d tokens per launch)" % tokens_call,
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(t_call * 1e3, 4)},

@@ -269,6 +269,19 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
 // steps, 4 LDS stages of 32 KiB (one workgroup per CU, three steps of DMA in flight).
 // LDS rows are 512 bytes (256 columns); the 32-byte chunk index is XOR-ed with 2 * (k & 3) as in
 // the 128-column image (only the low three bits matter for the banks).
+//
+// Schedule.  A step is two segments separated by workgroup barriers: R (the 24 transposing LDS
+// reads of the step) and M (its 16 MFMAs).  Waves 4..7 run one segment behind waves 0..3 (one
+// extra barrier in front of their loop, waves 0..3 take theirs at the end); waves w and w + 4
+// share a SIMD, so one of them is always in M while the other is in R: the matrix pipe has work
+// all the time and the partner's LDS traffic runs beside it.  The LDS-DMA loads of step t + 3 are
+// issued from inside M(t), one between every four MFMAs: there the wave only waits for the matrix
+// pipe, so issuing costs nothing and the address unit sees an even trickle (issued at the head of
+// a read segment the same loads delay the reads behind them by hundreds of cycles).
+// Ordering: stage (t+3) % 4 held step t-1, whose last reads (R(t-1) of waves 4..7) ended before a
+// barrier every wave has passed when it enters its M(t).  Every wave ends each R(s) with
+// vmcnt(4): all its DMA but the 4 youngest (step s+2) have landed, i.e. its share of step s+1 is in
+// LDS one barrier before waves 0..3 read it (their R(s+1)) and two before waves 4..7 do.
 constexpr int T2 = 256;
 constexpr int BK2 = 32;
 constexpr int NST2 = 4;
@@ -276,19 +289,15 @@ constexpr int OP2_BYTES = BK2 * T2 * 2;        // 16 KiB
 constexpr int STAGE2_BYTES = 2 * OP2_BYTES;    // 32 KiB
 constexpr int XTX2_LDS = NST2 * STAGE2_BYTES;  // 128 KiB
 
-__device__ __forceinline__ void stage_operand2(const unsigned short *__restrict__ x, int64_t ld, int64_t tok0, int col0,
-                                               char *lds_op, int wave, int lane)
+// wave-instruction `ii` (0..15) of one operand: 1 KiB = 2 token rows of 512 bytes
+__device__ __forceinline__ void stage_one2(const unsigned short *__restrict__ x, int64_t ld, int64_t tok0, int col0,
+                                           char *lds_op, int ii, int lane)
 {
-    // 16 wave-instructions of 1 KiB (= 2 token rows of 512 bytes), 2 per wave
     const int s = lane & 31;   // 16-byte slot in the row
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int ii = wave * 2 + it;
-        const int k = ii * 2 + (lane >> 5);
-        const int chunk = (s >> 1) ^ (2 * (k & 3));
-        const unsigned short *src = x + (tok0 + k) * ld + col0 + chunk * 16 + (s & 1) * 8;
-        __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_op + ii * 1024), 16, 0, 0);
-    }
+    const int k = ii * 2 + (lane >> 5);
+    const int chunk = (s >> 1) ^ (2 * (k & 3));
+    const unsigned short *src = x + (tok0 + k) * ld + col0 + chunk * 16 + (s & 1) * 8;
+    __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_op + ii * 1024), 16, 0, 0);
 }
 
 struct Frags2 {
@@ -310,8 +319,9 @@ __device__ __forceinline__ void read_step2(Frags2 &f, const unsigned (&addrA)[4]
     }
 }
 
-template <int DTYPE>
-__device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f)
+// the 8 MFMAs of one 16-token chunk; `between(0)` / `between(1)` run after the 2nd and the 6th
+template <int DTYPE, typename Hook>
+__device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f, Hook between)
 {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -320,6 +330,11 @@ __device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f)
             const s16x8 fa = __builtin_shufflevector(f.a[a][0], f.a[a][1], 0, 1, 2, 3, 4, 5, 6, 7);
             const s16x8 fb = __builtin_shufflevector(f.b[b][0], f.b[b][1], 0, 1, 2, 3, 4, 5, 6, 7);
             acc[a][b] = mfma16<DTYPE>(fa, fb, acc[a][b]);
+            if (b == 1 && (a == 0 || a == 2)) {
+                __builtin_amdgcn_sched_barrier(0);
+                between(a >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 }
 
@@ -368,23 +383,38 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
-    auto issue = [&](int kt, char *buf) {
-        stage_operand2(x, ld, (int64_t)kt * BK2, m0, buf, wave, lane);
-        stage_operand2(x, ld, (int64_t)kt * BK2, n0, buf + OP2_BYTES, wave, lane);
+    // this wave's 4 DMA instructions of step kt: 2 of the row-panel operand, 2 of the column-panel one
+    auto issue_one = [&](int kt, char *buf, int i) {
+        const int ii = wave * 2 + (i & 1);
+        if (i < 2) stage_one2(x, ld, (int64_t)kt * BK2, m0, buf, ii, lane);
+        else stage_one2(x, ld, (int64_t)kt * BK2, n0, buf + OP2_BYTES, ii, lane);
     };
 #pragma unroll
     for (int st = 0; st < NST2 - 1; ++st)
-        if (st < n_ktiles) issue(st, smem + st * STAGE2_BYTES);
+        if (st < n_ktiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_one(st, smem + st * STAGE2_BYTES, i);
+        }
+    // step 0 in LDS for everyone before the first read
+    if (n_ktiles >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n_ktiles == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool late = wave >= 4;   // wave-uniform
+    if (late) __builtin_amdgcn_s_barrier();
 
+    auto seg_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](auto cur_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
         constexpr int SB = cur * STAGE2_BYTES;
-        // 4 DMA instructions per wave per step; steps kt+1, kt+2 may stay in flight
-        if (n_ktiles - 1 - kt >= NST2 - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + NST2 - 1 < n_ktiles) issue(kt + NST2 - 1, smem + ((cur + NST2 - 1) % NST2) * STAGE2_BYTES);
+        // ---- R
         unsigned sA[4], sB[2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) sA[u] = addrA[u] + SB;
@@ -393,13 +423,18 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
         Frags2 f0, f1;
         read_step2<0>(f0, sA, sB);
         read_step2<16 * 512>(f1, sA, sB);
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step2<DTYPE>(acc, f0);
+        if (kt + 2 < n_ktiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step2<DTYPE>(acc, f1);
-        __builtin_amdgcn_sched_barrier(0);
+        seg_barrier();
+        // ---- M
+        const bool more = kt + NST2 - 1 < n_ktiles;
+        char *nbuf = smem + ((cur + NST2 - 1) % NST2) * STAGE2_BYTES;
+        __builtin_amdgcn_s_setprio(1);
+        mfma_step2<DTYPE>(acc, f0, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, i); });
+        mfma_step2<DTYPE>(acc, f1, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, 2 + i); });
+        __builtin_amdgcn_s_setprio(0);
+        seg_barrier();
     };
     int kt = 0;
     for (; kt + NST2 <= n_ktiles; kt += NST2) {
@@ -411,6 +446,7 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     if (kt < n_ktiles) step(std::integral_constant<int, 0>{}, kt++);
     if (kt < n_ktiles) step(std::integral_constant<int, 1>{}, kt++);
     if (kt < n_ktiles) step(std::integral_constant<int, 2>{}, kt++);
+    if (!late) __builtin_amdgcn_s_barrier();
 
     const bool do_mirror = mirror && (ti != tj);
     const int lrow = 4 * (lane >> 5), lcol = lane & 31;
@@ -589,13 +625,16 @@ int launch_xtx(float *hess, const unsigned short *x, int64_t n_tokens, int64_t h
         int rc;
         int variant = xtx_variant();
         if (variant < 0) {
-            // 256 x 256 tiles (one per CU) when they fill whole rounds of the 256 CUs well enough,
-            // else 128 x 128 tiles at three workgroups per CU
+            // 256 x 256 tiles at one workgroup per CU, or 128 x 128 tiles at two: whichever needs less
+            // time by a round count weighted with the measured time of a round (a full round of 256
+            // large tiles ~1.0, a round filling under 60 % of the CUs ~0.8, a round of 512 small tiles ~0.55)
             variant = 4;
             if (hidden % T2 == 0) {
-                const int64_t nt2 = hidden / T2, tiles = compute_lower_only ? nt2 * (nt2 + 1) / 2 : nt2 * nt2;
-                const int64_t rounds = gq_cdiv(tiles, 256);
-                if (tiles >= 512 && tiles * 5 >= rounds * 256 * 4) variant = 5;
+                const int64_t nt2 = hidden / T2, t256 = compute_lower_only ? nt2 * (nt2 + 1) / 2 : nt2 * nt2;
+                const int64_t nt1 = hidden / TM, t128 = compute_lower_only ? nt1 * (nt1 + 1) / 2 : nt1 * nt1;
+                const int64_t r256 = gq_cdiv(t256, 256), r128 = gq_cdiv(t128, 512);
+                const int64_t c256 = r256 * (t256 * 10 <= r256 * 256 * 6 ? 80 : 100), c128 = r128 * 55;
+                if (c256 < c128) variant = 5;
             }
         }
         switch (variant) {
