@@ -1,5 +1,5 @@
 // fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32: every output element is one
-// k-ascending fma chain).  128x128 tile per 256-thread workgroup, 2x2 waves of 64x64,
+// k-ascending fma chain).  128x128 (or 64x64) tile per 256-thread workgroup, 2x2 waves,
 // 32-deep k-steps staged global -> registers -> LDS (two LDS stages, one barrier per step; the
 // next step's global loads are issued before this step's MFMAs and written to LDS after them).
 //
@@ -11,23 +11,21 @@
 
 namespace {
 
-constexpr int BT = 128;   // tile edge
 constexpr int BKS = 32;   // k-step
-constexpr int IMG_FLOATS = BT * 33;             // the larger of the two images
-constexpr int SG_STAGE_FLOATS = 2 * IMG_FLOATS;  // A + B
-constexpr int SG_LDS_BYTES = 2 * SG_STAGE_FLOATS * 4;
 
 struct Prefetch {
     f32x4 v[4];
 };
 
-// k-contiguous source: rows of the tile are rows of the matrix.
+// k-contiguous source: rows of the tile are rows of the matrix.  BT rows x 32 k = BT/32 passes of
+// 256 threads x 4 floats.
+template <int BT>
 __device__ __forceinline__ void load_kcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
                                              int n_rows, int k0, int k_hi, int tid)
 {
     const int kq = (tid & 7) * 4;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < BT / 32; ++pass) {
         const int row = row0 + (tid >> 3) + 32 * pass;
         const int k = k0 + kq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -36,11 +34,12 @@ __device__ __forceinline__ void load_kcontig(Prefetch &p, const float *__restric
     }
 }
 
+template <int BT>
 __device__ __forceinline__ void store_kcontig(const Prefetch &p, float *img, int tid)
 {
     const int kq = (tid & 7) * 4;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < BT / 32; ++pass) {
         float *d = img + ((tid >> 3) + 32 * pass) * 33 + kq;
         d[0] = p.v[pass][0];
         d[1] = p.v[pass][1];
@@ -50,13 +49,16 @@ __device__ __forceinline__ void store_kcontig(const Prefetch &p, float *img, int
 }
 
 // row-contiguous source: rows of memory are k, the tile's rows run along memory columns.
+template <int BT>
 __device__ __forceinline__ void load_rcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
                                              int n_rows, int k0, int k_hi, int tid)
 {
-    const int rq = (tid & 31) * 4;
+    constexpr int TPR = BT / 4;            // threads per k-row
+    constexpr int KPP = 256 / TPR;         // k-rows per pass
+    const int rq = (tid % TPR) * 4;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int k = k0 + (tid >> 5) + 8 * pass;
+    for (int pass = 0; pass < BT / 32; ++pass) {
+        const int k = k0 + tid / TPR + KPP * pass;
         const int row = row0 + rq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < n_rows && k < k_hi) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)k * ld + row);
@@ -64,21 +66,30 @@ __device__ __forceinline__ void load_rcontig(Prefetch &p, const float *__restric
     }
 }
 
+template <int BT>
 __device__ __forceinline__ void store_rcontig(const Prefetch &p, float *img, int tid)
 {
-    const int rq = (tid & 31) * 4;
+    constexpr int TPR = BT / 4;
+    constexpr int KPP = 256 / TPR;
+    const int rq = (tid % TPR) * 4;
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass)
-        *reinterpret_cast<f32x4 *>(img + ((tid >> 5) + 8 * pass) * 128 + rq) = p.v[pass];
+    for (int pass = 0; pass < BT / 32; ++pass)
+        *reinterpret_cast<f32x4 *>(img + (tid / TPR + KPP * pass) * BT + rq) = p.v[pass];
 }
 
-template <int LAYOUT>
+// BT x BT output tile per 256-thread workgroup (BT = 128: 2x2 waves of 64x64; BT = 64: 2x2 waves of
+// 32x32, used when the 128-tile grid would leave most CUs idle).  The result does not depend on BT:
+// every element is the same k-ascending chain.
+template <int LAYOUT, int BT>
 __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
     constexpr bool A_KM = (LAYOUT & GQ_A_KM) != 0;
     constexpr bool B_KN = (LAYOUT & GQ_B_KN) != 0;
+    constexpr int WB = BT / 64;                     // MFMA blocks per wave and dimension
+    constexpr int IMG_FLOATS = BT * 33;             // the larger of the two images
+    constexpr int STAGE_FLOATS = 2 * IMG_FLOATS;    // A + B
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
     }
     const int m0 = tm * BT, n0 = tn * BT;
 
+    // the part of K this tile needs (one operand is triangular); bounds rounded to the tile edge
     int k_lo = 0, k_hi = g.k;
     if (g.trim == GQ_TRIM_K_LE_N) k_hi = min(g.k, (tn + 1) * BT);
     else if (g.trim == GQ_TRIM_K_GE_N) k_lo = min(g.k, tn * BT);
@@ -104,17 +116,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WB][WB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = 0.0f;
                 if (g.accumulate) {
-                    const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const int col = n0 + (wc * 2 + b) * 32 + li;
+                    const int row = m0 + (wr * WB + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int col = n0 + (wc * WB + b) * 32 + li;
                     if (row < g.m && col < g.n) v = g.c[(int64_t)row * g.ldc + col];
                 }
                 acc[a][b][e] = v;
@@ -125,17 +137,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
     Prefetch pa, pb;
     auto gload = [&](int step) {
         const int k0 = k_lo + step * BKS;
-        if constexpr (A_KM) load_rcontig(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
-        else load_kcontig(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
-        if constexpr (B_KN) load_rcontig(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
-        else load_kcontig(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
+        if constexpr (A_KM) load_rcontig<BT>(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
+        else load_kcontig<BT>(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
+        if constexpr (B_KN) load_rcontig<BT>(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
+        else load_kcontig<BT>(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
     };
     auto lstore = [&](int stage) {
-        float *ia = smem + stage * SG_STAGE_FLOATS, *ib = ia + IMG_FLOATS;
-        if constexpr (A_KM) store_rcontig(pa, ia, tid);
-        else store_kcontig(pa, ia, tid);
-        if constexpr (B_KN) store_rcontig(pb, ib, tid);
-        else store_kcontig(pb, ib, tid);
+        float *ia = smem + stage * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+        if constexpr (A_KM) store_rcontig<BT>(pa, ia, tid);
+        else store_kcontig<BT>(pa, ia, tid);
+        if constexpr (B_KN) store_rcontig<BT>(pb, ib, tid);
+        else store_kcontig<BT>(pb, ib, tid);
     };
 
     if (n_steps > 0) {
@@ -146,21 +158,21 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
     for (int step = 0; step < n_steps; ++step) {
         const int cur = step & 1;
         if (step + 1 < n_steps) gload(step + 1);
-        const float *ia = smem + cur * SG_STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+        const float *ia = smem + cur * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
 #pragma unroll 4
         for (int s = 0; s < BKS / 2; ++s) {
             const int k = 2 * s + lh;
-            float fa[2], fb[2];
+            float fa[WB], fb[WB];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ra = (wr * 2 + u) * 32 + li, rb = (wc * 2 + u) * 32 + li;
-                fa[u] = sgn * (A_KM ? ia[k * 128 + ra] : ia[ra * 33 + k]);
-                fb[u] = B_KN ? ib[k * 128 + rb] : ib[rb * 33 + k];
+            for (int u = 0; u < WB; ++u) {
+                const int ra = (wr * WB + u) * 32 + li, rb = (wc * WB + u) * 32 + li;
+                fa[u] = sgn * (A_KM ? ia[k * BT + ra] : ia[ra * 33 + k]);
+                fb[u] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < WB; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < WB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
         if (step + 1 < n_steps) lstore(cur ^ 1);
@@ -168,15 +180,36 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
     }
 
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int col = n0 + (wc * 2 + b) * 32 + li;
+                const int row = m0 + (wr * WB + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int col = n0 + (wc * WB + b) * 32 + li;
                 if (row < g.m && col < g.n) g.c[(int64_t)row * g.ldc + col] = acc[a][b][e];
             }
+}
+
+template <int BT>
+int launch_sgemm(const GqSgemmArgs &args, hipStream_t stream)
+{
+    constexpr int LDS_BYTES = 2 * 2 * BT * 33 * 4;
+    const int tiles_m = (args.m + BT - 1) / BT, tiles_n = (args.n + BT - 1) / BT;
+    GQ_REQUIRE(!args.lower_only || tiles_m == tiles_n, "sgemm: lower_only needs a square tile grid");
+    const int n_blocks = args.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    void (*kern)(GqSgemmArgs, int, int) = nullptr;
+    switch (args.layout) {
+    case GQ_A_MK | GQ_B_NK: kern = sgemm_kernel<GQ_A_MK | GQ_B_NK, BT>; break;
+    case GQ_A_MK | GQ_B_KN: kern = sgemm_kernel<GQ_A_MK | GQ_B_KN, BT>; break;
+    case GQ_A_KM | GQ_B_NK: kern = sgemm_kernel<GQ_A_KM | GQ_B_NK, BT>; break;
+    case GQ_A_KM | GQ_B_KN: kern = sgemm_kernel<GQ_A_KM | GQ_B_KN, BT>; break;
+    default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
+    }
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), LDS_BYTES, stream, args, tiles_m, tiles_n);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
 }
 
 }  // namespace
@@ -191,19 +224,9 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
                (long long)args.lda, (long long)args.ldb, (long long)args.ldc);
     GQ_REQUIRE((((uintptr_t)args.a | (uintptr_t)args.b | (uintptr_t)args.c) & 15) == 0, "sgemm: operands must be 16-byte aligned");
     if (args.m == 0 || args.n == 0) return GQ_OK;
-    const int tiles_m = (args.m + BT - 1) / BT, tiles_n = (args.n + BT - 1) / BT;
-    GQ_REQUIRE(!args.lower_only || tiles_m == tiles_n, "sgemm: lower_only needs a square tile grid");
-    const int n_blocks = args.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-    void (*kern)(GqSgemmArgs, int, int) = nullptr;
-    switch (args.layout) {
-    case GQ_A_MK | GQ_B_NK: kern = sgemm_kernel<GQ_A_MK | GQ_B_NK>; break;
-    case GQ_A_MK | GQ_B_KN: kern = sgemm_kernel<GQ_A_MK | GQ_B_KN>; break;
-    case GQ_A_KM | GQ_B_NK: kern = sgemm_kernel<GQ_A_KM | GQ_B_NK>; break;
-    case GQ_A_KM | GQ_B_KN: kern = sgemm_kernel<GQ_A_KM | GQ_B_KN>; break;
-    default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
-    }
-    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), SG_LDS_BYTES, stream, args, tiles_m, tiles_n);
-    GQ_LAUNCH_CHECK();
-    return GQ_OK;
+    // 128-tiles unless they would occupy fewer than the chip's 256 CUs
+    const int64_t tm = (args.m + 127) / 128, tn = (args.n + 127) / 128;
+    const int64_t blocks128 = args.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    if (blocks128 < 256) return launch_sgemm<64>(args, stream);
+    return launch_sgemm<128>(args, stream);
 }
