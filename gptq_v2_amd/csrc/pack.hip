@@ -112,6 +112,42 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const unsigned short 
     for (int64_t j = threadIdx.x; j < c; j += 256) out[m * c + j] = row[perm[j]];
 }
 
+// Wide variant (c a multiple of 8, c < 65536, 16-byte aligned rows): a workgroup keeps the
+// permutation in LDS as 16-bit indices and walks PR consecutive rows; rows are staged with 16-byte
+// loads, every thread gathers 8 neighbouring outputs from LDS and writes them with one 16-byte store.
+constexpr int PR = 16;
+__global__ __launch_bounds__(256) void permute_cols_wide_kernel(const unsigned short *__restrict__ x, const int32_t *__restrict__ perm,
+                                                                int64_t m, int64_t c, unsigned short *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short *pidx = (unsigned short *)smem;          // c entries
+    unsigned short *row = pidx + c;                          // 2 x c entries (two rows in flight)
+    const int tid = threadIdx.x;
+    for (int64_t j = tid; j < c; j += 256) pidx[j] = (unsigned short)perm[j];
+    const int64_t m_lo = (int64_t)blockIdx.x * PR, m_hi = m_lo + PR < m ? m_lo + PR : m;
+    auto stage = [&](int64_t mm, unsigned short *dst) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(x + mm * c);
+        for (int64_t j = tid; j < c / 8; j += 256) reinterpret_cast<u32x4 *>(dst)[j] = src[j];
+    };
+    if (m_lo < m_hi) stage(m_lo, row);
+    __syncthreads();
+    for (int64_t mm = m_lo; mm < m_hi; ++mm) {
+        unsigned short *cur = row + ((mm - m_lo) & 1) * c, *nxt = row + ((mm - m_lo + 1) & 1) * c;
+        if (mm + 1 < m_hi) stage(mm + 1, nxt);
+        for (int64_t j = tid; j < c / 8; j += 256) {
+            const u32x4 pi = reinterpret_cast<const u32x4 *>(pidx)[j];
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned lo = cur[pi[w] & 0xffffu], hi = cur[pi[w] >> 16];
+                o[w] = lo | (hi << 16);
+            }
+            reinterpret_cast<u32x4 *>(out + mm * c)[j] = o;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int bits, int layout, uint32_t *packed,
@@ -175,6 +211,14 @@ extern "C" int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t
     GQ_REQUIRE(m >= 0 && c > 0 && c <= 80 * 1024, "gq_permute_columns: bad shape");
     GQ_REQUIRE(x_in != x_out, "gq_permute_columns: in-place is not supported");
     if (m == 0) return GQ_OK;
+    if (c % 8 == 0 && c < 65536 && c * 6 <= 150 * 1024 && (((uintptr_t)x_in | (uintptr_t)x_out) & 15) == 0) {
+        const size_t lds_w = (size_t)(c * 6);
+        GQ_HIP(hipFuncSetAttribute((const void *)permute_cols_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        hipLaunchKernelGGL(permute_cols_wide_kernel, dim3((unsigned)gq_cdiv(m, PR)), dim3(256), lds_w, (hipStream_t)stream,
+                           (const unsigned short *)x_in, perm, m, c, (unsigned short *)x_out);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    }
     const size_t lds = (size_t)((c * 2 + 15) & ~15);
     GQ_HIP(hipFuncSetAttribute((const void *)permute_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)m), dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_in, perm, c, (unsigned short *)x_out);

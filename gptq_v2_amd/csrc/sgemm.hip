@@ -101,6 +101,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
         while (r * (r + 1) / 2 > bid) --r;
         tm = r;
         tn = bid - r * (r + 1) / 2;
+    } else if (g.trim == GQ_TRIM_K_LE_N) {
+        // tiles differ in the length of their K range: walk them longest first, so that the last
+        // round of workgroups is made of the short ones
+        tn = tiles_n - 1 - (int)(blockIdx.x / tiles_m);
+        tm = blockIdx.x % tiles_m;
+    } else if (g.trim == GQ_TRIM_K_GE_N) {
+        tn = blockIdx.x / tiles_m;
+        tm = blockIdx.x % tiles_m;
+    } else if (g.trim == GQ_TRIM_K_LE_M) {
+        tm = tiles_m - 1 - (int)(blockIdx.x / tiles_n);
+        tn = blockIdx.x % tiles_n;
     } else {
         tm = blockIdx.x / tiles_n;
         tn = blockIdx.x % tiles_n;

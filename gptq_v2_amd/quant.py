@@ -208,13 +208,27 @@ class QuantLinear(nn.Module):
                 "scale_bit_width": None}
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def permute_input(self, x: torch.Tensor) -> torch.Tensor:
+        """x[..., perm]: the activation gather of act-order.  Layers quantised against the same
+        Hessian (q/k/v, gate/up) share ``perm``, so their caller can do this once and use
+        ``forward_permuted`` on each of them."""
+        if x.dtype != torch.float16:
+            raise NotImplementedError("QuantLinear takes float16 activations")
         shape = x.shape
-        x2 = x.reshape(-1, shape[-1])
-        if x2.dtype != torch.float16:
-            raise NotImplementedError("QuantLinear.forward takes float16 activations")
-        x2 = x2.contiguous()
+        x2 = x.reshape(-1, shape[-1]).contiguous()
         if self.perm is not None:
             x2 = ops.permute_columns(x2, self.perm)
-        y = ops.w4a16_gemm(x2, self.qweight, self.scales, self.qzeros, self.group_size)
+        return x2.reshape(shape)
+
+    @torch.no_grad()
+    def forward_permuted(self, x_permuted: torch.Tensor) -> torch.Tensor:
+        shape = x_permuted.shape
+        x2 = x_permuted.reshape(-1, shape[-1])
+        if x2.dtype != torch.float16:
+            raise NotImplementedError("QuantLinear takes float16 activations")
+        y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size)
         return y.reshape(*shape[:-1], self.out_features)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward_permuted(self.permute_input(x))

@@ -453,6 +453,30 @@ def test_w4a16_gemm_group_sizes_and_ragged_tiles(amd, gpu, m, r, c, gsz):
     assert (y.double() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("m,c", [(37, 4096), (5, 11008), (16, 264), (33, 100), (1, 8), (2048, 4096)])
+def test_permute_columns_exact(amd, gpu, m, c):
+    """Column gather of 16-bit activations (act-order): exact for both code paths (16-byte path
+    for c % 8 == 0, element path otherwise), ragged row counts, fp16 and bf16."""
+    gen = torch.Generator().manual_seed(m * 7 + c)
+    perm = torch.randperm(c, generator=gen)
+    for dt in (torch.float16, torch.bfloat16):
+        x = torch.randn(m, c, generator=gen).to(dt)
+        got = amd.ops.permute_columns(x.to(gpu), perm.to(torch.int32).to(gpu)).cpu()
+        assert torch.equal(got.view(torch.int16), x[:, perm].contiguous().view(torch.int16))
+
+
+def test_quantlinear_shared_permuted_input(amd, gpu):
+    """Linears that share an input share its act-order: permute once, feed every layer."""
+    g = load_golden("f5_kernelsem_64x256_b4")
+    meta = {"qweight": t(g["qweight"]), "scale": t(g["scale"]), "qzero": t(g["qzero"]), "perm_inv": t(g["perm_inv"]),
+            "group_sizes": t(g["meta_group_sizes"]), "group_bit_widths": t(g["meta_group_bit_widths"])}
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    x = torch.randn(2, 70, 256, generator=torch.Generator().manual_seed(3)).half().to(gpu)
+    xp = layer.permute_input(x)
+    assert xp.shape == x.shape
+    assert torch.equal(layer(x), layer.forward_permuted(xp))
+
+
 def test_c_abi_rejects_bad_arguments(amd, gpu):
     h = torch.zeros(128, 128, device=gpu)
     with pytest.raises(ValueError):
