@@ -89,18 +89,29 @@ def make_inputs(dev, n_local, seed):
     return xs, ws
 
 
+VERBOSE = bool(os.environ.get("GQ_BENCH_VERBOSE"))
+
+
+def note(rank, msg):
+    if VERBOSE:
+        print("[rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+
 def run_block(amd, gd, xs, ws, batch, phases, rank, world):
     """The hot path of one decoder block on this rank's share of samples and rows."""
     dev = xs[HIDDEN].device
     for (c, outs), weights in zip(SETS, ws):
+        note(rank, "set C=%d" % c)
         x = xs[c]
         hook = amd.HessianHook()
         for bi in range(0, x.shape[0], batch):
             with phases["xtx_%d" % c]:
                 hook.add_batch(x[bi:bi + batch])
         if world > 1:
+            note(rank, "allreduce")
             with phases["allreduce"]:
                 hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
+        note(rank, "invert")
         with phases["invert"]:
             hook.invert(damp_ratio=1e-2, act_order=True)
         gs = torch.full([c // 128], 128, dtype=torch.int32)
@@ -114,6 +125,7 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
                                      gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev)
                 meta = res["quant_meta"]
             if world > 1:
+                note(rank, "allgather")
                 with phases["allgather"]:
                     full = gd.allgather_rows({k: meta[k] for k in ("qweight", "scale", "qzero")}, r)
                     meta = dict(meta, **full)
@@ -181,12 +193,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # GQ_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
+    # devices, collectives go through gloo): it checks the multi-rank code path, not its speed.
+    backend = os.environ.get("GQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import gptq_v2_amd as amd
     from gptq_v2_amd import dist as gd
 

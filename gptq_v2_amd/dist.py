@@ -66,6 +66,9 @@ def allgather_rows(local: Dict[str, torch.Tensor], n_rows: int, multiple: int = 
         mine = torch.zeros((most,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
         mine[: part.shape[0]] = part
         gathered = torch.empty((ws, most) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-        dist.all_gather_into_tensor(gathered.view(ws * most, *part.shape[1:]), mine)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(gathered.view(ws * most, *part.shape[1:]), mine)
+        else:   # gloo (CPU tests, single-GPU rehearsals): the list form is the one it implements everywhere
+            dist.all_gather([gathered[r] for r in range(ws)], mine)
         out[name] = torch.cat([gathered[r, : e - b] for r, (b, e) in enumerate(bounds)], dim=0)
     return out
