@@ -523,22 +523,21 @@ __global__ __launch_bounds__(256) void xtx_generic_kernel(float *__restrict__ he
 
 // Tile order: the (lower triangle of the) nt x nt tile grid cut into SUPER x SUPER super-tiles,
 // super-tiles row-major, tiles row-major inside each.  Entry = (tile_row << 16) | tile_col.
-constexpr int SUPER_TILE = 12;
-
 struct TileTable {
-    int device, nt, lower, n_blocks;
+    int device, nt, lower, super, n_blocks;
     uint32_t *dev;
 };
 
-int get_tile_table(int nt, int lower, const uint32_t **out, int *n_blocks_out)
+int get_tile_table(int nt, int lower, int SUPER_TILE, const uint32_t **out, int *n_blocks_out)
 {
+    if (const char *e = getenv("GQ_XTX_SUPERTILE")) SUPER_TILE = std::max(1, atoi(e));   // experiment knob
     static std::mutex mu;
     static std::vector<TileTable> cache;
     int device = 0;
     GQ_HIP(hipGetDevice(&device));
     std::lock_guard<std::mutex> lock(mu);
     for (const TileTable &t : cache)
-        if (t.device == device && t.nt == nt && t.lower == lower) {
+        if (t.device == device && t.nt == nt && t.lower == lower && t.super == SUPER_TILE) {
             *out = t.dev;
             *n_blocks_out = t.n_blocks;
             return GQ_OK;
@@ -550,7 +549,7 @@ int get_tile_table(int nt, int lower, const uint32_t **out, int *n_blocks_out)
             for (int ti = si * SUPER_TILE; ti < std::min(nt, (si + 1) * SUPER_TILE); ++ti)
                 for (int tj = sj * SUPER_TILE; tj < std::min(nt, (sj + 1) * SUPER_TILE); ++tj)
                     if (!lower || tj <= ti) host.push_back(((uint32_t)ti << 16) | (uint32_t)tj);
-    TileTable t{device, nt, lower, (int)host.size(), nullptr};
+    TileTable t{device, nt, lower, SUPER_TILE, (int)host.size(), nullptr};
     GQ_HIP(hipMalloc((void **)&t.dev, host.size() * sizeof(uint32_t)));
     GQ_HIP(hipMemcpy(t.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     cache.push_back(t);
@@ -568,7 +567,7 @@ int launch_mfma(float *hess, const unsigned short *x, int64_t n_tokens, int64_t 
     const int n_ktiles = (int)(n_tokens / BKT);
     const uint32_t *table = nullptr;
     int n_blocks = 0;
-    int rc = get_tile_table(nt, compute_lower_only, &table, &n_blocks);
+    int rc = get_tile_table(nt, compute_lower_only, 12, &table, &n_blocks);
     if (rc) return rc;
     GQ_HIP(hipFuncSetAttribute((const void *)xtx_mfma_kernel<DTYPE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipLaunchKernelGGL((xtx_mfma_kernel<DTYPE, BKT, NST>), dim3(n_blocks), dim3(256), LDS, stream, hess, x, (int)hidden,
@@ -586,7 +585,9 @@ int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64
     const int n_ktiles = (int)(n_tokens / BK2);
     const uint32_t *table = nullptr;
     int n_blocks = 0;
-    int rc = get_tile_table(nt, compute_lower_only, &table, &n_blocks);
+    // 6 x 6 super-tiles: the ~32 tiles an XCD runs at a time (one per CU) then span about 12 column
+    // panels of X instead of 64, and the XCD's L2 serves the rest (measured: fewest memory-side bytes)
+    int rc = get_tile_table(nt, compute_lower_only, 6, &table, &n_blocks);
     if (rc) return rc;
     GQ_HIP(hipFuncSetAttribute((const void *)xtx256_kernel<DTYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
     hipLaunchKernelGGL(xtx256_kernel<DTYPE>, dim3(n_blocks), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles,
