@@ -117,13 +117,16 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
         gs = torch.full([c // 128], 128, dtype=torch.int32)
         gb = torch.full([c // 128], 4, dtype=torch.int32)
         layers = []
-        for w in weights:
+        shards = [gd.row_shard(w.shape[0], rank, world) for w in weights]
+        with phases["quant"]:
+            # the Linears of the set share U: all of them are enqueued (row slices on side streams)
+            # before the first result is waited for
+            results = amd.gptq_quant_set([w[rb:re] for w, (rb, re) in zip(weights, shards)], hook, gs, gb,
+                                         scale_bit_width=None, gptq_use_kernel=True, gptq_block_sizes=gs,
+                                         quant_symmetric=False, quant_mse=False, save_device=dev)
+        for w, res in zip(weights, results):
             r = w.shape[0]
-            rb, re = gd.row_shard(r, rank, world)
-            with phases["quant"]:
-                res = amd.gptq_quant(w[rb:re], hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
-                                     gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev)
-                meta = res["quant_meta"]
+            meta = res["quant_meta"]
             if world > 1:
                 note(rank, "allgather")
                 with phases["allgather"]:
@@ -134,7 +137,8 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
                 del lin
             with phases["pack"]:
                 layers.append(amd.QuantLinear.from_quant_meta(meta, dev))
-            del meta, res
+            del meta
+        del results
         # replay (llama.py:176-177): the Linears of a set share the input and its act-order, so each
         # batch is gathered into permuted column order once and fed to every layer of the set
         for bi in range(0, x.shape[0], batch):

@@ -62,6 +62,131 @@ class HessianHook:
         return self.hessian_inv
 
 
+# The Linears that share a Hessian are independent given U (and so are the rows of one Linear).
+# The column loop is a chain of short kernels (one block of <= 128 columns, then its trailing
+# update) that leaves most of the chip idle, so the Linears of a set run on separate HIP streams
+# and fill each other's gaps (measured on the Llama-2-7B block: 32.6 -> 27.4 ms).  Slicing the
+# rows of ONE Linear over streams does not pay: a slice's chain is barely shorter than the whole
+# layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1.
+# HIP gives a process 4 hardware queues by default: more streams would only be serialised again.
+N_QUANT_STREAMS = 4
+ROW_SLICES = 1
+MIN_SLICE_ROWS = 256
+_streams: dict = {}
+
+
+def _side_streams(device: torch.device) -> list:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _streams:
+        _streams[key] = [torch.cuda.Stream(device=device) for _ in range(N_QUANT_STREAMS)]
+    return _streams[key]
+
+
+def _row_slices(n_rows: int, want: int) -> list:
+    want = max(1, min(want, n_rows // MIN_SLICE_ROWS))
+    step = -(-n_rows // want)
+    step = -(-step // 64) * 64   # the block kernel works on 64-row groups
+    return [(b, min(n_rows, b + step)) for b in range(0, n_rows, step)]
+
+
+@torch.no_grad()
+def gptq_quant_set(
+        weights,
+        hessian_hook: Optional[HessianHook],
+        group_sizes: torch.Tensor,
+        group_bit_widths: torch.Tensor,
+        scale_bit_width: torch.Tensor = None,
+        gptq_use_kernel: bool = True,
+        gptq_block_sizes: torch.Tensor = None,
+        quant_symmetric: bool = False,
+        quant_mse: bool = True,
+        quant_max_shrink: float = .8,
+        quant_n_grid: int = 100,
+        quant_norm: float = 2.4,
+        quant_use_kernel: bool = False,
+        save_device: torch.device = torch.device('cpu'),
+) -> list:
+    """``gptq_quant`` for every weight of ``weights`` against ONE Hessian -- the Linears of an
+    input-sharing set, which the reference quantises one after the other (llama.py:150-170).
+    Same arguments and, per weight, the same result dictionary as ``gptq_quant``; the work of all
+    of them is enqueued on side streams before anything is waited for."""
+    if scale_bit_width is not None:
+        raise NotImplementedError("EXL2 scale quantisation (scale_bit_width) is not supported")
+    if quant_mse:
+        raise NotImplementedError("quant_mse grid search is not supported (llama.py runs with quant_mse=False)")
+    gs = _group_list(group_sizes)
+    gb = _group_list(group_bit_widths)
+    if hessian_hook is not None and not gptq_use_kernel:
+        if gptq_block_sizes is None or _group_list(gptq_block_sizes) != gs:
+            raise NotImplementedError("the PyTorch-loop semantics are implemented for gptq_block_sizes == group_sizes")
+    weights = list(weights)
+    if not weights:
+        return []
+    device = weights[0].device
+    perm32 = None
+    u = None
+    if hessian_hook is not None:
+        u = hessian_hook.hessian_inv
+        if hessian_hook.perm is not None:
+            perm32 = hessian_hook.perm.to(torch.int32).contiguous()
+        # gptq_py.py:95-96 zeroes columns whose Hessian diagonal is 0; after invert() no diagonal
+        # entry is 0 any more (dead ones were set to 1, then damped), so nothing is zeroed there either.
+    sem = ops.SEM_KERNEL if gptq_use_kernel else ops.SEM_PYTHON
+
+    main = torch.cuda.current_stream(device)
+    side = _side_streams(device)
+    for st in side:
+        st.wait_stream(main)   # inputs were produced on the caller's stream; earlier results of ours were read there
+    per_weight = ROW_SLICES
+    jobs = []   # (weight index, row range, result tensors, metric sums)
+    k = 0
+    for wi, weight in enumerate(weights):
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        for b, e in _row_slices(w.shape[0], per_weight):
+            with torch.cuda.stream(side[k % len(side)]):
+                res = ops.quantize_layer(w[b:e], perm32, u, gs, gb, sym=quant_symmetric, semantics=sem,
+                                         want_quant=True, want_error=hessian_hook is not None)
+                sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"])
+            jobs.append((wi, res, sums))
+            k += 1
+    for st in side:
+        main.wait_stream(st)
+
+    out = []
+    for wi, weight in enumerate(weights):
+        mine = [j for j in jobs if j[0] == wi]
+        n_rows, n_columns = weight.shape
+        dtype = weight.dtype
+        cat = (lambda name: mine[0][1][name]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0))
+        sums = torch.stack([j[2] for j in mine]).sum(dim=0).tolist()
+        n = float(n_rows * n_columns)
+        gptq_error = sums[0] / n
+        metrics = {
+            "gptq_error": gptq_error,
+            "gptq_norm": sums[1] / n if hessian_hook is not None else gptq_error,
+            "l2.0_error": sums[2] / n,
+            # the reference takes this mean in the weight's 16-bit dtype (gptq_py.py:237)
+            "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(dtype).item(),
+        }
+        if perm32 is not None:
+            perm_inv = hessian_hook.perm_inv.to(torch.int16)
+        else:
+            perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
+        quant_meta = {
+            "qweight": cat("qweight").to(device=save_device),
+            "scale": cat("scale").to(device=save_device),
+            "qzero": cat("qzero").to(device=save_device),
+            "qscale": None,
+            "sscale": None,
+            "perm_inv": perm_inv.to(device=save_device),
+            "group_sizes": torch.as_tensor(gs, dtype=torch.int16, device=save_device),
+            "group_bit_widths": torch.as_tensor(gb, dtype=torch.uint8, device=save_device),
+            "scale_bit_width": None,
+        }
+        out.append({"quant_meta": quant_meta, "metrics": metrics})
+    return out
+
+
 @torch.no_grad()
 def gptq_quant(
         weight: torch.Tensor,
@@ -83,59 +208,9 @@ def gptq_quant(
     native loop (grid from the unmodified weights, fp16 dequantisation), ``False`` those of its
     pure-PyTorch loop (grid from the error-compensated weights, fp32 dequantisation);
     ``hessian_hook=None`` rounds to nearest.  Returns {'quant_meta': ..., 'metrics': ...}."""
-    if scale_bit_width is not None:
-        raise NotImplementedError("EXL2 scale quantisation (scale_bit_width) is not supported")
-    if quant_mse:
-        raise NotImplementedError("quant_mse grid search is not supported (llama.py runs with quant_mse=False)")
-    n_rows, n_columns = weight.shape
-    dtype = weight.dtype
-    device = weight.device
-    gs = _group_list(group_sizes)
-    gb = _group_list(group_bit_widths)
-    if hessian_hook is not None and not gptq_use_kernel:
-        if gptq_block_sizes is None or _group_list(gptq_block_sizes) != gs:
-            raise NotImplementedError("the PyTorch-loop semantics are implemented for gptq_block_sizes == group_sizes")
-    w = weight if weight.is_contiguous() else weight.contiguous()
-
-    perm32 = None
-    u = None
-    if hessian_hook is not None:
-        u = hessian_hook.hessian_inv
-        if hessian_hook.perm is not None:
-            perm32 = hessian_hook.perm.to(torch.int32).contiguous()
-        # gptq_py.py:95-96 zeroes columns whose Hessian diagonal is 0; after invert() no diagonal
-        # entry is 0 any more (dead ones were set to 1, then damped), so nothing is zeroed there either.
-    res = ops.quantize_layer(w, perm32, u, gs, gb, sym=quant_symmetric,
-                             semantics=ops.SEM_KERNEL if gptq_use_kernel else ops.SEM_PYTHON,
-                             want_quant=True, want_error=hessian_hook is not None)
-    sums = ops.quant_metrics(w, perm32, u, res["quant_t"], res["error_t"]).tolist()
-    n = float(n_rows * n_columns)
-    gptq_error = sums[0] / n
-    metrics = {
-        "gptq_error": gptq_error,
-        "gptq_norm": sums[1] / n if hessian_hook is not None else gptq_error,
-        "l2.0_error": sums[2] / n,
-        # the reference takes this mean in the weight's 16-bit dtype (gptq_py.py:237)
-        "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(dtype).item(),
-    }
-
-    if perm32 is not None:
-        perm = hessian_hook.perm.to(torch.int16)
-        perm_inv = hessian_hook.perm_inv.to(torch.int16)
-    else:
-        perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
-    quant_meta = {
-        "qweight": res["qweight"].to(device=save_device),
-        "scale": res["scale"].to(device=save_device),
-        "qzero": res["qzero"].to(device=save_device),
-        "qscale": None,
-        "sscale": None,
-        "perm_inv": perm_inv.to(device=save_device),
-        "group_sizes": torch.as_tensor(gs, dtype=torch.int16, device=save_device),
-        "group_bit_widths": torch.as_tensor(gb, dtype=torch.uint8, device=save_device),
-        "scale_bit_width": None,
-    }
-    return {"quant_meta": quant_meta, "metrics": metrics}
+    return gptq_quant_set([weight], hessian_hook, group_sizes, group_bit_widths, scale_bit_width, gptq_use_kernel,
+                          gptq_block_sizes, quant_symmetric, quant_mse, quant_max_shrink, quant_n_grid, quant_norm,
+                          quant_use_kernel, save_device)[0]
 
 
 class GPTQ:

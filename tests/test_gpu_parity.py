@@ -477,6 +477,37 @@ def test_quantlinear_shared_permuted_input(amd, gpu):
     assert torch.equal(layer(x), layer.forward_permuted(xp))
 
 
+def test_gptq_quant_set_matches_single_calls_and_row_slices(amd, gpu):
+    """Linears sharing a Hessian quantised together (side streams) give exactly what one call per
+    Linear gives; so does a Linear cut into row slices."""
+    import gptq_v2_amd.gptq_py as gp
+    gen = torch.Generator().manual_seed(21)
+    c = 512
+    x = (torch.randn(4, 300, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half().to(gpu)
+    hook = amd.HessianHook()
+    hook.add_batch(x)
+    hook.invert()
+    ws = [(torch.randn(r, c, generator=gen) * 0.02).half().to(gpu) for r in (640, 256, 1024)]
+    gs = torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.full([c // 128], 4, dtype=torch.int32)
+    kw = dict(gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu)
+    single = [amd.gptq_quant(w, hook, gs, gb, **kw) for w in ws]
+    together = amd.gptq_quant_set(ws, hook, gs, gb, **kw)
+    old = gp.ROW_SLICES
+    try:
+        gp.ROW_SLICES = 3
+        sliced = amd.gptq_quant_set(ws, hook, gs, gb, **kw)
+    finally:
+        gp.ROW_SLICES = old
+    for a, b, c_ in zip(single, together, sliced):
+        for k in ("qweight", "scale", "qzero", "perm_inv"):
+            assert torch.equal(a["quant_meta"][k], b["quant_meta"][k]), k
+            assert torch.equal(a["quant_meta"][k], c_["quant_meta"][k]), k
+        for k in a["metrics"]:
+            assert b["metrics"][k] == pytest.approx(a["metrics"][k], rel=1e-12), k
+            assert c_["metrics"][k] == pytest.approx(a["metrics"][k], rel=1e-6), k
+
+
 def test_c_abi_rejects_bad_arguments(amd, gpu):
     h = torch.zeros(128, 128, device=gpu)
     with pytest.raises(ValueError):
