@@ -13,6 +13,7 @@
 // The update of the columns behind the block is an fp32 MFMA GEMM (sgemm.hip) whose per-element
 // operation order (k ascending, fused multiply-add, starting from the old weight) is the same as
 // the in-block updates', so the result does not depend on how columns are cut into blocks.
+#include <type_traits>
 #include <vector>
 
 #include "sgemm.h"
@@ -52,6 +53,33 @@ __device__ __forceinline__ void grid_from_minmax(float lo, float hi, float amax,
     }
 }
 
+// Correctly rounded a / b from rb = RN(1 / b): q0 = RN(a * rb) is within one ulp of the quotient,
+// the residual a - b * q0 is exact in one fma, and one more fma lands on the correctly rounded
+// quotient (the classic fma division; three dependent instructions instead of the ~14 of the
+// IEEE sequence hipcc emits for `/`).  Its proof needs a correctly rounded reciprocal and no
+// underflow in the residual, so: the reciprocals are taken in double precision and rounded once
+// (exact for a 24-bit divisor, see recip_rn), and a sub-block that met an operand outside
+// 2^-97 .. 2^93 -- or a divisor outside 2^-60 .. 2^60, flagged by rb = NaN -- is walked again with
+// the plain division (its inputs are still untouched in LDS).
+__device__ __forceinline__ float recip_rn(float b)
+{
+    // RN(1/b): the double quotient carries 53 bits; it cannot sit within 2^-53 of a 25-bit midpoint
+    // m unless b * m is a power of two, so rounding it again to 24 bits never double-rounds.
+    const unsigned e = (__float_as_uint(b) >> 23) & 0xffu;
+    if (e < 67u || e > 187u) return __uint_as_float(0x7fc00000u);
+    return (float)(1.0 / (double)b);
+}
+
+// fast form, no branch: `bad` collects the operands the proof does not cover
+__device__ __forceinline__ float div_rn_fast(float a, float b, float rb, bool &bad)
+{
+    const unsigned e = (__float_as_uint(a) >> 23) & 0xffu;
+    bad |= ((e - 30u) > 190u && a != 0.0f) || (rb != rb);
+    const float q0 = __fmul_rn(a, rb);
+    const float rem = fmaf(-b, q0, a);
+    return fmaf(rem, rb, q0);
+}
+
 // SEM == GQ_SEM_KERNEL: fp16 dequantisation, fused update.  GQ_SEM_PYTHON: fp32, mul then sub.
 //
 // One 256-thread workgroup owns 64 output features (lane = feature) and one block of <= 128
@@ -63,7 +91,15 @@ __device__ __forceinline__ void grid_from_minmax(float lo, float hi, float amax,
 // over the waves SUB columns at a time.  Every weight still sees its updates in ascending column
 // order, one fma each, so the cut into sub-blocks does not change any bit.
 constexpr int ULD = QB + 4;   // stride of the U square in LDS
-constexpr int QB_LDS = (QB * 64 + QB * ULD) * 4;
+constexpr int QB_LDS = (QB * 64 + QB * ULD + QB) * 4;   // weights, U square, reciprocals of its diagonal
+
+#ifdef GQ_QB_TRACE
+// Debug build only (tools/trace_qb.py): cycle stamps of workgroup 0.
+__device__ unsigned long long *g_qb_trace = nullptr;
+#define QB_TR(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define QB_TR(i)
+#endif
 
 template <int SEM, int SUB>
 __global__ __launch_bounds__(256) void quant_block_kernel(
@@ -72,26 +108,63 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
     int a, int bs, float maxq, int q_is_u8, int write_back, int dynamic, int sym)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef GQ_QB_TRACE
+    unsigned long long ts[40] = {};
+    QB_TR(0);
+#endif
     float (*wl)[64] = reinterpret_cast<float (*)[64]>(smem_raw);
     float *ul = reinterpret_cast<float *>(smem_raw) + QB * 64;
+    float *rdl = ul + QB * ULD;   // RN(1 / U[c][c]) of the block's columns
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t r = (int64_t)blockIdx.x * 64 + lane;
     const bool live = r < r_total;
     const int64_t rr = live ? r : r_total - 1;   // dead lanes shadow the last row and store nothing
-    for (int c = wv; c < bs; c += 4) wl[c][lane] = wt[(int64_t)(a + c) * r_total + rr];
+    // Everything the block needs, fetched with all loads in flight at once (a load-store loop would
+    // pay one memory latency per iteration): the wave's 32 weight columns, the thread's 16 quads
+    // of the U square, the grid.
+    // Addresses are a wave-uniform 64-bit base plus a 32-bit per-lane offset (the host checks that
+    // 128 columns of R rows and 128 rows of U stay below 2^30 elements): 64-bit multiplies per
+    // load cost more than the loads.
+    float s = 0.0f, z = 0.0f;
+    if (!dynamic) {
+        s = scale[rr];
+        z = zero[rr];
+    }
+    const unsigned rt = (unsigned)r_total, lu = (unsigned)ldu;
+    const float *__restrict__ wbase = wt + (int64_t)a * r_total;
+    const float *__restrict__ ubase = u + (int64_t)a * ldu + a;
     {
-        const int q4 = bs / 4;   // float4 per row of the square
-        for (int e = tid; e < bs * q4; e += 256) {
-            const int row = e / q4, c4 = (e - row * q4) * 4;
-            *reinterpret_cast<f32x4 *>(ul + row * ULD + c4) =
-                *reinterpret_cast<const f32x4 *>(u + (int64_t)(a + row) * ldu + a + c4);
+        float wreg[QB / 4];
+#pragma unroll
+        for (int i = 0; i < QB / 4; ++i) {
+            const int c = wv + 4 * i;
+            wreg[i] = c < bs ? wbase[(unsigned)c * rt + (unsigned)rr] : 0.0f;
         }
+        const int trow = tid >> 5, c4 = (tid & 31) * 4;
+        const unsigned uoff = (unsigned)trow * lu + (unsigned)c4;
+        f32x4 ureg[QB / 8];
+#pragma unroll
+        for (int i = 0; i < QB / 8; ++i) {
+            const int row = trow + 8 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < bs && c4 < bs) v = *reinterpret_cast<const f32x4 *>(ubase + (uoff + (unsigned)(8 * i) * lu));
+            ureg[i] = v;
+        }
+        const float dg = tid < bs ? ubase[(unsigned)tid * lu + (unsigned)tid] : 1.0f;
+        QB_TR(34);
+#pragma unroll
+        for (int i = 0; i < QB / 4; ++i) wl[wv + 4 * i][lane] = wreg[i];
+#pragma unroll
+        for (int i = 0; i < QB / 8; ++i) *reinterpret_cast<f32x4 *>(ul + (trow + 8 * i) * ULD + c4) = ureg[i];
+        QB_TR(35);
+        if (tid < bs) rdl[tid] = recip_rn(dg);
+        QB_TR(36);
     }
     __syncthreads();
+    QB_TR(37);
 
-    float s, z;
     if (dynamic) {
         float lo = 3.4e38f, hi = -3.4e38f, am = 0.0f;
         for (int c = 0; c < bs; ++c) {
@@ -105,85 +178,157 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
             scale[r] = s;
             zero[r] = z;
         }
-    } else {
-        s = scale[rr];
-        z = zero[rr];
     }
-    const bool writer = live && wv == 0;
+    const float rs = recip_rn(s);
+    QB_TR(1);
 
     const int n_sub = bs / SUB;
     for (int jb = 0; jb < n_sub; ++jb) {
         const int c0 = jb * SUB;   // first column of the sub-block
         float w[SUB], nerr[SUB], deq[SUB], qv[SUB];
+        // FAST: divisions by fma from precomputed reciprocals, straight-line; else the plain ones
+        auto walk = [&](auto fast_c) -> bool {
+            constexpr bool FAST = decltype(fast_c)::value;
+            bool bad = false;
 #pragma unroll
-        for (int i = 0; i < SUB; ++i) w[i] = wl[c0 + i][lane];
-#pragma unroll
-        for (int i = 0; i < SUB; ++i) {
-            const float x = w[i];
-            const float qf = clampf(rintf(x / s) + z, 0.0f, maxq);
-            float dq;
-            if constexpr (SEM == GQ_SEM_KERNEL) {
-                const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
-                _Float16 hd = hx - hz;
-                hd = hd * hs;
-                dq = (float)hd;
-            } else {
-                dq = __fmul_rn(__fsub_rn(qf, z), s);
-            }
-            const float d = ul[(c0 + i) * ULD + c0 + i];
-            const float err = (x - dq) / d;
-            qv[i] = qf;
-            deq[i] = dq;
-            nerr[i] = SEM == GQ_SEM_KERNEL ? -err : err;
-#pragma unroll
-            for (int i2 = i + 1; i2 < SUB; ++i2) {
-                const float uv = ul[(c0 + i) * ULD + c0 + i2];
-                if constexpr (SEM == GQ_SEM_KERNEL) w[i2] = fmaf(nerr[i], uv, w[i2]);
-                else w[i2] = __fsub_rn(w[i2], __fmul_rn(nerr[i], uv));
-            }
-        }
-        if (writer) {
+            for (int i = 0; i < SUB; ++i) w[i] = wl[c0 + i][lane];
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
-                const int64_t o = (int64_t)(a + c0 + i) * r_total + r;
-                error_t[o] = SEM == GQ_SEM_KERNEL ? -nerr[i] : nerr[i];
-                if (quant_t) quant_t[o] = deq[i];
-                if (write_back) wt[o] = w[i];
-            }
-            if (q_out) {
-                if (q_is_u8) {
-#pragma unroll
-                    for (int i = 0; i < SUB; ++i) ((uint8_t *)q_out)[(int64_t)(a + c0 + i) * r_total + r] = (uint8_t)qv[i];
+                const float x = w[i];
+                float quo;
+                if constexpr (FAST) quo = div_rn_fast(x, s, rs, bad);
+                else quo = x / s;
+                const float qf = clampf(rintf(quo) + z, 0.0f, maxq);
+                float dq;
+                if constexpr (SEM == GQ_SEM_KERNEL) {
+                    const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
+                    _Float16 hd = hx - hz;
+                    hd = hd * hs;
+                    dq = (float)hd;
                 } else {
+                    dq = __fmul_rn(__fsub_rn(qf, z), s);
+                }
+                const float d = ul[(c0 + i) * ULD + c0 + i];
+                float err;
+                if constexpr (FAST) err = div_rn_fast(x - dq, d, rdl[c0 + i], bad);
+                else err = (x - dq) / d;
+                qv[i] = qf;
+                deq[i] = dq;
+                nerr[i] = SEM == GQ_SEM_KERNEL ? -err : err;
 #pragma unroll
-                    for (int i = 0; i < SUB; ++i) ((int16_t *)q_out)[(int64_t)(a + c0 + i) * r_total + r] = (int16_t)(uint16_t)qv[i];
+                for (int i2 = i + 1; i2 < SUB; ++i2) {
+                    const float uv = ul[(c0 + i) * ULD + c0 + i2];
+                    if constexpr (SEM == GQ_SEM_KERNEL) w[i2] = fmaf(nerr[i], uv, w[i2]);
+                    else w[i2] = __fsub_rn(w[i2], __fmul_rn(nerr[i], uv));
+                }
+            }
+            return bad;
+        };
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(walk(std::true_type{})) != 0, 0)) walk(std::false_type{});
+#ifdef GQ_QB_TRACE
+        if (jb < 8) QB_TR(2 + jb * 4);
+#endif
+        // outputs of the sub-block: every wave holds all of them, wave w stores columns i = w mod 4
+        if (live) {
+            const int64_t col0 = (int64_t)(a + c0) * r_total;   // wave-uniform
+            float *__restrict__ eb = error_t + col0;
+            float *__restrict__ qb = quant_t ? quant_t + col0 : nullptr;
+            float *__restrict__ wb = wt + col0;
+            uint8_t *__restrict__ q8 = (uint8_t *)q_out + col0;
+            int16_t *__restrict__ q16 = (int16_t *)q_out + col0;
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                if ((i & 3) != wv) continue;
+                const unsigned o = (unsigned)i * rt + (unsigned)r;
+                eb[o] = SEM == GQ_SEM_KERNEL ? -nerr[i] : nerr[i];
+                if (quant_t) qb[o] = deq[i];
+                if (write_back) wb[o] = w[i];
+                if (q_out) {
+                    if (q_is_u8) q8[o] = (uint8_t)qv[i];
+                    else q16[o] = (int16_t)(uint16_t)qv[i];
                 }
             }
         }
-        // the rest of the block, SUB columns at a time, one chunk per wave
-        for (int cb = jb + 1 + wv; cb < n_sub; cb += 4) {
-            const int d0 = cb * SUB;
-            float v[SUB];
+#ifdef GQ_QB_TRACE
+        if (jb < 8) QB_TR(3 + jb * 4);
+#endif
+        if constexpr (SEM == GQ_SEM_KERNEL) {
+            // The rest of the block on the matrix core: W^T[c'][r] += sum_k U[c0+k][c'] * nerr[k][r]
+            // as 32 (columns) x 32 (rows) output blocks of v_mfma_f32_32x32x2_f32 -- per element the
+            // same ascending-k chain of fused multiply-adds as the scalar form.  Column blocks are
+            // aligned to 32, so the first one may cover columns that are already final: those are
+            // computed and not stored (a slower wave may still be reading them).  A operand: U from LDS.  B operand: lane l
+            // holds nerr[.] of row l; the swap below puts (k even, rows 0..31 | k odd, rows 0..31)
+            // into the lanes of one register and the same for rows 32..63 into the other.
+            const int li = lane & 31, lh = lane >> 5;
+            float b0[SUB / 2], b1[SUB / 2];
 #pragma unroll
-            for (int j = 0; j < SUB; ++j) v[j] = wl[d0 + j][lane];
+            for (int sidx = 0; sidx < SUB / 2; ++sidx) {
+                const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(nerr[2 * sidx]),
+                                                                 __float_as_uint(nerr[2 * sidx + 1]), false, false);
+                b0[sidx] = __uint_as_float(pr[0]);
+                b1[sidx] = __uint_as_float(pr[1]);
+            }
+            const int cb_lo = (c0 + SUB) >> 5, n_cb = (bs + 31) >> 5;
+            for (int t = wv; t < (n_cb - cb_lo) * 2; t += 4) {
+                const int cblk = cb_lo + (t >> 1), rb = t & 1;
+                f32x16 acc;
 #pragma unroll
-            for (int k = 0; k < SUB; ++k) {
+                for (int e = 0; e < 16; ++e) acc[e] = wl[cblk * 32 + 8 * (e >> 2) + (e & 3) + 4 * lh][rb * 32 + li];
 #pragma unroll
-                for (int j4 = 0; j4 < SUB; j4 += 4) {
-                    const f32x4 uv = *reinterpret_cast<const f32x4 *>(ul + (c0 + k) * ULD + d0 + j4);
+                for (int sidx = 0; sidx < SUB / 2; ++sidx) {
+                    const float av = ul[(c0 + 2 * sidx + lh) * ULD + cblk * 32 + li];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, rb ? b1[sidx] : b0[sidx], acc, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if constexpr (SEM == GQ_SEM_KERNEL) v[j4 + e] = fmaf(nerr[k], uv[e], v[j4 + e]);
-                        else v[j4 + e] = __fsub_rn(v[j4 + e], __fmul_rn(nerr[k], uv[e]));
+                for (int e = 0; e < 16; ++e) {
+                    const int col = cblk * 32 + 8 * (e >> 2) + (e & 3) + 4 * lh;
+                    if (col >= c0 + SUB) wl[col][rb * 32 + li] = acc[e];   // columns already final stay as they are
+                }
+            }
+        } else {
+            // the rest of the block, SUB columns at a time, one chunk per wave
+            for (int cb = jb + 1 + wv; cb < n_sub; cb += 4) {
+                const int d0 = cb * SUB;
+                float v[SUB];
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) v[j] = wl[d0 + j][lane];
+#pragma unroll
+                for (int k = 0; k < SUB; ++k) {
+#pragma unroll
+                    for (int j4 = 0; j4 < SUB; j4 += 4) {
+                        const f32x4 uv = *reinterpret_cast<const f32x4 *>(ul + (c0 + k) * ULD + d0 + j4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j4 + e] = __fsub_rn(v[j4 + e], __fmul_rn(nerr[k], uv[e]));
                     }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < SUB; ++j) wl[d0 + j][lane] = v[j];
+                for (int j = 0; j < SUB; ++j) wl[d0 + j][lane] = v[j];
+            }
         }
+#ifdef GQ_QB_TRACE
+        if (jb < 8) QB_TR(4 + jb * 4);
+#endif
         __syncthreads();
+#ifdef GQ_QB_TRACE
+        if (jb < 8) QB_TR(5 + jb * 4);
+#endif
     }
+#ifdef GQ_QB_TRACE
+    if (g_qb_trace && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 38; ++i) g_qb_trace[wv * 40 + i] = ts[i];
+    }
+#endif
 }
+
+#ifdef GQ_QB_TRACE
+extern "C" int gq_debug_qb_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qb_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+#endif
 
 // ---- grid for all groups from the unmodified weights (static groups) ------------------------
 __global__ void find_params_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0, int64_t ncols,
@@ -505,6 +650,7 @@ extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_
     GQ_REQUIRE(quant && scale && qzero && hessian_inv && weights && error, "gq_quantize_range: NULL pointer");
     GQ_REQUIRE(c > 0 && r > 0 && 0 <= a && a <= b && b <= c, "gq_quantize_range: bad range [%lld, %lld) of %lld",
                (long long)a, (long long)b, (long long)c);
+    GQ_REQUIRE(r <= (1 << 22) && c <= (1 << 22), "gq_quantize_range: at most 2^22 rows and columns");
     GQ_REQUIRE(r % 4 == 0 && c % 4 == 0 && (b - a) % 4 == 0 && a % 4 == 0,
                "gq_quantize_range: out_features, in_features and the range must be multiples of 4");
     hipStream_t stream = (hipStream_t)stream_;
@@ -541,6 +687,7 @@ extern "C" int gq_quantize_layer(const void *weight, int dtype, const int32_t *p
     GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quantize_layer: bad dtype %d", dtype);
     GQ_REQUIRE(semantics == GQ_SEM_KERNEL || semantics == GQ_SEM_PYTHON, "gq_quantize_layer: bad semantics %d", semantics);
     GQ_REQUIRE(r > 0 && c > 0 && r % 4 == 0, "gq_quantize_layer: out_features %lld must be a positive multiple of 4", (long long)r);
+    GQ_REQUIRE(r <= (1 << 22) && c <= (1 << 22), "gq_quantize_layer: at most 2^22 rows and columns");
     int rc = check_groups(group_sizes_host, group_bits_host, n_groups, c, "gq_quantize_layer");
     if (rc) return rc;
     if (semantics == GQ_SEM_PYTHON)   // the grid is computed inside the block kernel: one block per group

@@ -338,12 +338,25 @@ __device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f,
         }
 }
 
+#ifdef GQ_XTX_TRACE
+// Debug build only (tools/trace_xtx.py): per-wave cycle stamps of one workgroup.
+__device__ unsigned long long *g_xtx_trace = nullptr;
+#define XT_TR(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define XT_TR(i)
+#endif
+
 template <int DTYPE>
 __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
                                                      int hidden, int n_ktiles, const uint32_t *__restrict__ tile_table,
                                                      int n_blocks, int mirror)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef GQ_XTX_TRACE
+    unsigned long long ts[12] = {};
+    XT_TR(0);
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -421,12 +434,17 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
 #pragma unroll
         for (int u = 0; u < 2; ++u) sB[u] = addrB[u] + SB;
         Frags2 f0, f1;
+        XT_TR(2);
         read_step2<0>(f0, sA, sB);
         read_step2<16 * 512>(f1, sA, sB);
+        XT_TR(3);
         if (kt + 2 < n_ktiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XT_TR(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        XT_TR(5);
         seg_barrier();
+        XT_TR(6);
         // ---- M
         const bool more = kt + NST2 - 1 < n_ktiles;
         char *nbuf = smem + ((cur + NST2 - 1) % NST2) * STAGE2_BYTES;
@@ -434,8 +452,11 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
         mfma_step2<DTYPE>(acc, f0, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, i); });
         mfma_step2<DTYPE>(acc, f1, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, 2 + i); });
         __builtin_amdgcn_s_setprio(0);
+        XT_TR(7);
         seg_barrier();
+        XT_TR(8);
     };
+    XT_TR(1);
     int kt = 0;
     for (; kt + NST2 <= n_ktiles; kt += NST2) {
         step(std::integral_constant<int, 0>{}, kt);
@@ -447,23 +468,57 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     if (kt < n_ktiles) step(std::integral_constant<int, 1>{}, kt++);
     if (kt < n_ktiles) step(std::integral_constant<int, 2>{}, kt++);
     if (!late) __builtin_amdgcn_s_barrier();
+    XT_TR(9);
 
+    // H[tile] += acc, one 32 x 32 accumulator block at a time: its 16 loads are issued together
+    // (one memory latency per block, not per element).  Register e of a lane is row
+    // 8*(e>>2) + (e&3) + 4*(lane>>5), column lane&31 of the block, so in the mirrored tile the
+    // four registers e&3 = 0..3 are four consecutive floats of one row: one 16-byte store.
     const bool do_mirror = mirror && (ti != tj);
     const int lrow = 4 * (lane >> 5), lcol = lane & 31;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            const int row0 = m0 + (wr * 4 + a) * 32 + lrow;
+            const int col = n0 + (wc * 2 + b) * 32 + lcol;
+            float *p0 = hess + (int64_t)row0 * ld + col;
+            float old[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (wr * 4 + a) * 32 + (e & 3) + 8 * (e >> 2) + lrow;
-                const int col = n0 + (wc * 2 + b) * 32 + lcol;
-                float *p = hess + (int64_t)row * ld + col;
-                const float v = *p + acc[a][b][e];
-                *p = v;
-                if (do_mirror) hess[(int64_t)col * ld + row] = v;
+            for (int e = 0; e < 16; ++e) old[e] = p0[(int64_t)((e & 3) + 8 * (e >> 2)) * ld];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) old[e] += acc[a][b][e];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) p0[(int64_t)((e & 3) + 8 * (e >> 2)) * ld] = old[e];
+            if (do_mirror) {
+                float *q0 = hess + (int64_t)col * ld + row0;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4)
+                    *reinterpret_cast<f32x4 *>(q0 + 8 * e4) = f32x4{old[4 * e4], old[4 * e4 + 1], old[4 * e4 + 2], old[4 * e4 + 3]};
             }
+        }
+#ifdef GQ_XTX_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XT_TR(10);
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+    if (g_xtx_trace && blockIdx.x == 40 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) g_xtx_trace[wave * 16 + i] = ts[i];
+        g_xtx_trace[wave * 16 + 11] = tr0;
+        g_xtx_trace[wave * 16 + 12] = tr1;
+    }
+#endif
 }
+
+#ifdef GQ_XTX_TRACE
+}  // namespace
+extern "C" int gq_debug_xtx_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xtx_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+namespace {
+#endif
 
 // Generic path: any hidden size, any token range [tok0, tok1).  64x64 output tile per 256-thread
 // workgroup, 4x4 outputs per thread, fp32 fma in token order.  Used for the token tail that does
