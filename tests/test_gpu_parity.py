@@ -239,6 +239,31 @@ def test_quantize_range_bit_exact_with_c_restatement(amd, oracle, gpu, c, r, a, 
                                 got["w"], got["err"], a, b)
 
 
+@pytest.mark.parametrize("wscale,uscale", [(1e-33, 1.0), (1.0, 1e-25), (1e30, 1.0), (1e-20, 1e18)])
+def test_quantize_range_extreme_magnitudes_take_the_plain_division(amd, oracle, gpu, wscale, uscale):
+    """The column walk divides by fma from reciprocals; operands outside the range its proof
+    covers (tiny / huge weights, a tiny or huge U diagonal) must fall back to the IEEE division
+    and stay bit-identical to the C restatement."""
+    c, r, a, b = 128, 64, 0, 128
+    u = (_spd_factor(c, 5) * uscale).contiguous()
+    gen = torch.Generator().manual_seed(77)
+    w_t = (torch.randn(c, r, generator=gen) * 0.02 * wscale).contiguous()
+    scale, zero, maxq = oracle.find_params(w_t[a:b].t(), 4)
+    scale, zero = scale[:, 0].contiguous(), zero[:, 0].contiguous()
+    want = dict(quant=torch.zeros(c, r), q=torch.zeros(c, r, dtype=torch.int16), w=w_t.clone(), err=torch.zeros(c, r))
+    oracle.quantize_range_kernel(want["quant"], scale, want["q"], zero, maxq, u, want["w"], want["err"], a, b)
+    got = dict(quant=torch.zeros(c, r, device=gpu), q=torch.zeros(c, r, dtype=torch.int16, device=gpu),
+               w=w_t.clone().to(gpu), err=torch.zeros(c, r, device=gpu))
+    amd.gptq_quantize_range(got["quant"], scale.to(gpu), got["q"], zero.to(gpu), maxq, u.to(gpu), got["w"], got["err"], a, b)
+    assert torch.equal(got["q"].cpu(), want["q"])
+    for k in ("quant", "err", "w"):
+        # the overflowing case produces inf and NaN: they must appear in the same places (the sign
+        # of a NaN is the one thing an x86 host and the GPU do not agree on), everything else bitwise
+        g_, w_ = got[k].cpu(), want[k]
+        assert torch.equal(g_.isnan(), w_.isnan()), k
+        assert torch.equal(torch.nan_to_num(g_, nan=0.0).view(torch.int32), torch.nan_to_num(w_, nan=0.0).view(torch.int32)), k
+
+
 # ------------------------------------------------------------------------------------------
 # gptq_quant
 # ------------------------------------------------------------------------------------------
@@ -360,6 +385,40 @@ def test_end_to_end_hook_and_quant_llama_shape(amd, oracle, gpu):
         assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
     for k in ("gptq_error", "gptq_norm", "l2.0_error", "l2.0_norm"):
         assert res["metrics"][k] == pytest.approx(want["metrics"][k], rel=1e-4), k
+
+
+@pytest.mark.parametrize("dtype,groups,bits,sym,act", [
+    (torch.bfloat16, [128, 128, 128], [4, 4, 4], False, True),
+    (torch.float16, [128, 64, 64, 128], [4, 3, 8, 2], False, True),
+    (torch.float16, [32] * 8, [4] * 8, True, False),
+    (torch.bfloat16, [96, 96, 64], [3, 4, 4], True, True),
+])
+def test_gptq_quant_kernel_semantics_variants_match_oracle(amd, oracle, gpu, dtype, groups, bits, sym, act):
+    """bf16 weights, mixed group sizes and bit widths, symmetric grids, with and without
+    act-order: the GPU's U and perm go into the CPU oracle, every output identical."""
+    c, r = sum(groups), 200
+    gen = torch.Generator().manual_seed(c + r + len(groups))
+    x = (torch.randn(3, 400, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).to(dtype).to(gpu)
+    w = (torch.randn(r, c, generator=gen) * 0.02).to(dtype).to(gpu)
+    hook = amd.HessianHook()
+    hook.add_batch(x)
+    hook.invert(act_order=act)
+    gs, gb = torch.tensor(groups, dtype=torch.int32), torch.tensor(bits, dtype=torch.int32)
+    res = amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_symmetric=sym, quant_mse=False)
+    oh = oracle.OracleHessian()
+    oh.hessian = hook.hessian.cpu()
+    oh.hessian_inv = hook.hessian_inv.cpu()
+    if act:
+        oh.perm, oh.perm_inv = hook.perm.cpu(), hook.perm_inv.cpu()
+    want = oracle.gptq_quant(w.cpu(), oh, gs, gb, use_kernel_semantics=True, symmetric=sym)
+    for k in ("qweight", "scale", "qzero", "perm_inv", "group_sizes", "group_bit_widths"):
+        assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
+    assert res["quant_meta"]["scale"].dtype == dtype
+    for k in ("gptq_error", "gptq_norm", "l2.0_error", "l2.0_norm"):
+        assert res["metrics"][k] == pytest.approx(want["metrics"][k], rel=1e-4), k
+    lin = amd.reconstruct_nn_linear(res["quant_meta"], dtype=dtype, device=gpu)
+    assert torch.equal(lin.weight.data.cpu().view(torch.int16),
+                       oracle.construct_weight(want["quant_meta"], dtype).view(torch.int16))
 
 
 # ------------------------------------------------------------------------------------------
