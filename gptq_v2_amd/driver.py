@@ -1,0 +1,227 @@
+"""Block-wise GPTQ driver for Llama-family decoders, on the HIP hot path.
+
+What the reference's ``llama.py`` does with its Catcher / RecorderWrapper machinery
+(llama.py:20-204, model_utils.py:69-109): walk the decoder blocks in order; inside a block
+quantise the Linears in the order their inputs become available --
+``[q, k, v] -> [o] -> [gate, up] -> [down]`` -- one Hessian per input-sharing set, every set seeing
+the outputs of the sets already quantised before it; then run the quantised block to produce the
+next block's inputs.  The result dictionary has the reference's shape
+``{'data': {name: quant_meta}, 'metrics': {name: metrics}}`` (llama.py:82-85, 167-173).
+
+Differences in construction, not in result: inputs are captured with forward pre-hooks (the block
+is re-run up to the hooked Linear, which is cheap next to the quantisation) instead of the
+reference's fake-tensor dependency discovery, the Linears of a set are quantised together
+(``gptq_quant_set``), and everything stays on the GPU.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from .gptq_py import HessianHook, gptq_quant_set
+from .quant import QuantLinear, reconstruct_weight
+
+# Linears of one Llama decoder block in dependency order; each inner list shares its input.
+LLAMA_SETS: List[List[str]] = [
+    ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"],
+    ["self_attn.o_proj"],
+    ["mlp.gate_proj", "mlp.up_proj"],
+    ["mlp.down_proj"],
+]
+
+
+class _Stop(Exception):
+    """Raised from a pre-hook once the wanted input has been seen: the rest of the forward is not needed."""
+
+    def __init__(self, args=(), kwargs=None):
+        super().__init__("stop")
+        self.call_args, self.call_kwargs = args, kwargs or {}
+
+
+def _to_device(obj, device):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return {k: _to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_device(v, device) for v in obj)
+    return obj
+
+
+def _first(out):
+    """Decoder blocks return a tensor or a tuple whose first entry is the hidden state."""
+    return out[0] if isinstance(out, (tuple, list)) else out
+
+
+def _submodule(block: nn.Module, dotted: str) -> nn.Module:
+    mod = block
+    for part in dotted.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+@torch.no_grad()
+def get_initial_inputs(model: nn.Module, encodings: torch.Tensor, device: torch.device,
+                       batch_size: int = 1) -> Tuple[torch.Tensor, dict]:
+    """Inputs of the first decoder block for every calibration sequence, and the keyword
+    arguments the model passes to its blocks (llama.py:20-61).  encodings (B, N) int64."""
+    blocks = model.model.layers
+    use_cache, model.config.use_cache = model.config.use_cache, False
+    model.model.embed_tokens.to(device)
+    if getattr(model.model, "rotary_emb", None) is not None:
+        model.model.rotary_emb.to(device)
+
+    def catch(_mod, args, kwargs):
+        raise _Stop(args, kwargs)
+
+    handle = blocks[0].register_forward_pre_hook(catch, with_kwargs=True)
+    inps, inp_kwargs = [], {}
+    try:
+        for bi in range(0, len(encodings), batch_size):
+            try:
+                model(encodings[bi:bi + batch_size].to(device))
+            except _Stop as stop:
+                hidden = stop.call_args[0] if stop.call_args else stop.call_kwargs["hidden_states"]
+                inps.append(hidden)
+                inp_kwargs = {k: v for k, v in stop.call_kwargs.items() if k != "hidden_states"}
+    finally:
+        handle.remove()
+        model.config.use_cache = use_cache
+    return torch.cat(inps, dim=0), inp_kwargs
+
+
+@torch.no_grad()
+def quantize_llama(
+        model: nn.Module,
+        encodings: torch.Tensor,
+        device: torch.device,
+        batch_size: int = 1,
+        bits: int = 4,
+        group_size: int = 128,
+        act_order: bool = True,
+        damp_ratio: float = 1e-2,
+        pack: bool = False,
+        sets: Sequence[Sequence[str]] = LLAMA_SETS,
+        on_set: Optional[Callable] = None,
+) -> Dict[str, Dict[str, dict]]:
+    """Quantise every decoder block of ``model`` in place (llama.py:64-204).
+
+    After the call each Linear holds the dense reconstructed weight (what the reference leaves in
+    the model), or is replaced by a packed ``QuantLinear`` when ``pack`` is set.  ``on_set(block
+    index, names, hessian_hook, weights)`` is called after each set's Hessian is inverted and
+    before its weights change (for inspection and tests)."""
+    inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
+    inp_kwargs = _to_device(inp_kwargs, device)
+    use_cache, model.config.use_cache = model.config.use_cache, False
+    dtype = inps.dtype
+    results: Dict[str, Dict[str, dict]] = {"data": {}, "metrics": {}, "seconds_per_block": []}
+
+    for gi, block in enumerate(model.model.layers):
+        t0 = time.time()
+        block.to(device)
+        for names in sets:
+            mods = [_submodule(block, n) for n in names]
+            hook = HessianHook()
+
+            def feed(_mod, args, _hook=hook):
+                _hook.add_batch(args[0])
+                raise _Stop()
+
+            handle = mods[0].register_forward_pre_hook(feed)
+            try:
+                for bi in range(0, len(inps), batch_size):
+                    try:
+                        block(inps[bi:bi + batch_size], **inp_kwargs)
+                    except _Stop:
+                        pass
+            finally:
+                handle.remove()
+            hook.invert(damp_ratio=damp_ratio, act_order=act_order)
+
+            weights = [m.weight.data for m in mods]
+            c = weights[0].shape[1]
+            if c % group_size:
+                raise ValueError(f"in_features {c} is not a multiple of the group size {group_size}")
+            gs = torch.full([c // group_size], group_size, dtype=torch.int32)
+            gb = torch.full([c // group_size], bits, dtype=torch.int32)
+            if on_set is not None:
+                on_set(gi, list(names), hook, weights)
+            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
+                                  gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=device)
+            for name, mod, res in zip(names, mods, outs):
+                canonical = f"model.layers.{gi}.{name}"
+                meta = res["quant_meta"]
+                results["metrics"][canonical] = res["metrics"]
+                results["data"][canonical] = _to_device(meta, torch.device("cpu"))
+                if pack:
+                    layer = QuantLinear.from_quant_meta(meta, device)
+                    parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
+                    setattr(parent, name.rsplit(".", 1)[-1], layer)
+                else:
+                    mod.weight.data = reconstruct_weight(meta, dtype, device)
+            del hook, outs
+
+        nxt = torch.empty_like(inps)
+        for bi in range(0, len(inps), batch_size):
+            nxt[bi:bi + batch_size] = _first(block(inps[bi:bi + batch_size], **inp_kwargs))
+        inps = nxt
+        results["seconds_per_block"].append(time.time() - t0)
+
+    model.config.use_cache = use_cache
+    return results
+
+
+@torch.no_grad()
+def evaluate_llama(model: nn.Module, encodings: torch.Tensor, device: torch.device, batch_size: int = 1) -> torch.Tensor:
+    """Perplexity over ``encodings`` (B, N), block by block as the reference evaluates
+    (llama.py:207-247): mean over sequences of the per-batch token cross-entropy, exponentiated."""
+    inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
+    inp_kwargs = _to_device(inp_kwargs, device)
+    use_cache, model.config.use_cache = model.config.use_cache, False
+    for block in model.model.layers:
+        block.to(device)
+        nxt = torch.empty_like(inps)
+        for bi in range(0, len(inps), batch_size):
+            nxt[bi:bi + batch_size] = _first(block(inps[bi:bi + batch_size], **inp_kwargs))
+        inps = nxt
+    if getattr(model.model, "norm", None) is not None:
+        model.model.norm.to(device)
+        for bi in range(0, len(inps), batch_size):
+            inps[bi:bi + batch_size] = model.model.norm(inps[bi:bi + batch_size])
+    model.lm_head.to(device)
+    loss = nn.CrossEntropyLoss()
+    nlls = []
+    for bi in range(0, len(inps), batch_size):
+        logits = model.lm_head(inps[bi:bi + batch_size])
+        labels = encodings[bi:bi + batch_size, 1:].to(device)
+        nll = loss(logits[:, :-1, :].flatten(end_dim=-2).float(), labels.flatten())
+        nlls.extend([nll] * len(logits))
+    model.config.use_cache = use_cache
+    return torch.stack(nlls).to(torch.float32).mean().exp()
+
+
+def save_results(results: Dict[str, Dict[str, dict]], path: str) -> None:
+    """The reference's on-disk format (main.py:37-38): ``torch.save`` of
+    ``{'data': {name: quant_meta}, 'metrics': {name: metrics}}`` -- tensors, numbers and None only,
+    so the file loads with ``torch.load(path, weights_only=True)``."""
+    torch.save({"data": results["data"], "metrics": results["metrics"]}, path)
+
+
+@torch.no_grad()
+def load_results_into(model: nn.Module, results_or_path, device: torch.device, pack: bool = True,
+                      dtype: torch.dtype = torch.float16) -> nn.Module:
+    """Puts saved ``quant_meta`` entries (names ``model.layers.<i>.<linear>``) back into a model:
+    packed ``QuantLinear`` layers, or dense reconstructed weights as the reference evaluates
+    them (quant.py:262-279)."""
+    res = torch.load(results_or_path, weights_only=True) if isinstance(results_or_path, str) else results_or_path
+    for name, meta in res["data"].items():
+        parent_name, leaf = name.rsplit(".", 1)
+        parent = model.get_submodule(parent_name)
+        if pack:
+            setattr(parent, leaf, QuantLinear.from_quant_meta(meta, device))
+        else:
+            getattr(parent, leaf).weight.data = reconstruct_weight(meta, dtype, device)
+    return model

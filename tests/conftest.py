@@ -37,3 +37,17 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def amd(gpu):
+    """The product package; importing it loads libgptq_amd.so (GPU tests only)."""
+    import gptq_v2_amd
+    return gptq_v2_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement, as the checker."""
+    from oracle import gptq_oracle
+    return gptq_oracle

@@ -1,0 +1,125 @@
+"""Block-wise driver on a tiny random-initialised Llama (no checkpoint, no dataset): result
+format, per-layer agreement with the CPU oracle given the same Hessian factor, and the point of
+the whole exercise -- GPTQ beats round-to-nearest on the calibration loss."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_llama(seed=0):
+    transformers = pytest.importorskip("transformers")
+    cfg = transformers.LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                                   num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+                                   tie_word_embeddings=False)
+    torch.manual_seed(seed)
+    model = transformers.LlamaForCausalLM(cfg).half().eval()
+    return model
+
+
+def _rtn_copy(amd, model, gpu):
+    from gptq_v2_amd import driver
+    m = copy.deepcopy(model)
+    for block in m.model.layers:
+        block.to(gpu)
+        for names in driver.LLAMA_SETS:
+            for n in names:
+                mod = driver._submodule(block, n)
+                c = mod.weight.shape[1]
+                gs = torch.full([c // 128], 128, dtype=torch.int32)
+                gb = torch.full([c // 128], 4, dtype=torch.int32)
+                res = amd.gptq_quant(mod.weight.data, None, gs, gb, quant_mse=False, save_device=gpu)
+                mod.weight.data = amd.quant.reconstruct_weight(res["quant_meta"], torch.float16, gpu)
+    return m
+
+
+def test_quantize_tiny_llama_end_to_end(amd, oracle, gpu):
+    from gptq_v2_amd import driver
+    model = _tiny_llama()
+    gen = torch.Generator().manual_seed(1)
+    enc = torch.randint(0, 512, (16, 96), generator=gen)
+    ppl_fp = float(driver.evaluate_llama(copy.deepcopy(model), enc, gpu, batch_size=4))
+
+    seen = []
+
+    def on_set(gi, names, hook, weights):
+        # the first set of the first block and the last set of the last block go through the oracle
+        if (gi, names[0]) in ((0, "self_attn.q_proj"), (1, "mlp.down_proj")):
+            seen.append((gi, names, hook.hessian.cpu(), hook.hessian_inv.cpu(), hook.perm.cpu(), hook.perm_inv.cpu(), [w.clone().cpu() for w in weights]))
+
+    qmodel = copy.deepcopy(model)
+    res = driver.quantize_llama(qmodel, enc, gpu, batch_size=4, on_set=on_set)
+
+    names = [f"model.layers.{gi}.{n}" for gi in range(2) for s in driver.LLAMA_SETS for n in s]
+    assert sorted(res["data"]) == sorted(names) and sorted(res["metrics"]) == sorted(names)
+    meta = res["data"]["model.layers.1.mlp.down_proj"]
+    assert meta["qweight"].shape == (256, 512) and meta["qweight"].dtype == torch.uint8 and meta["qweight"].device.type == "cpu"
+    assert meta["scale"].shape == (256, 4) and meta["scale"].dtype == torch.float16
+    assert meta["perm_inv"].dtype == torch.int16 and meta["group_sizes"].tolist() == [128] * 4
+    assert set(res["metrics"][names[0]]) == {"gptq_error", "gptq_norm", "l2.0_error", "l2.0_norm"}
+
+    # the captured sets through the CPU oracle with the same U and perm: identical integers
+    assert len(seen) == 2
+    for gi, set_names, h, u, perm, perm_inv, weights in seen:
+        oh = oracle.OracleHessian()
+        oh.hessian, oh.hessian_inv, oh.perm, oh.perm_inv = h, u, perm, perm_inv
+        for n, w in zip(set_names, weights):
+            c = w.shape[1]
+            gs = torch.full([c // 128], 128, dtype=torch.int32)
+            gb = torch.full([c // 128], 4, dtype=torch.int32)
+            want = oracle.gptq_quant(w, oh, gs, gb, use_kernel_semantics=True)["quant_meta"]
+            got = res["data"][f"model.layers.{gi}.{n}"]
+            for k in ("qweight", "scale", "qzero", "perm_inv"):
+                assert torch.equal(got[k], want[k]), (gi, n, k)
+
+    # the quantised model holds exactly the reconstructed weights
+    w_model = qmodel.model.layers[0].self_attn.q_proj.weight.data.cpu()
+    assert torch.equal(w_model, oracle.construct_weight(res["data"]["model.layers.0.self_attn.q_proj"], torch.float16))
+
+    ppl_gptq = float(driver.evaluate_llama(qmodel, enc, gpu, batch_size=4))
+    ppl_rtn = float(driver.evaluate_llama(_rtn_copy(amd, model, gpu), enc, gpu, batch_size=4))
+    assert ppl_fp > 1.0 and abs(ppl_gptq - ppl_fp) / ppl_fp < 0.05
+    # error-compensated rounding is closer to the fp16 model than plain rounding on the calibration set
+    assert abs(ppl_gptq - ppl_fp) <= abs(ppl_rtn - ppl_fp) + 1e-3 * ppl_fp
+
+
+def test_quantize_tiny_llama_packed_layers_agree_with_dense(amd, gpu):
+    from gptq_v2_amd import driver
+    model = _tiny_llama(seed=3)
+    enc = torch.randint(0, 512, (8, 64), generator=torch.Generator().manual_seed(2))
+    dense, packed = copy.deepcopy(model), copy.deepcopy(model)
+    r1 = driver.quantize_llama(dense, enc, gpu, batch_size=4)
+    r2 = driver.quantize_llama(packed, enc, gpu, batch_size=4, pack=True)
+    assert isinstance(packed.model.layers[0].mlp.down_proj, amd.QuantLinear)
+    # block 0 sees identical inputs in both runs, so its first set must agree exactly; later sets see
+    # activations that went through the packed GEMM (fp32 accumulation order differs from the dense one)
+    for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"):
+        k = f"model.layers.0.{n}"
+        assert torch.equal(r1["data"][k]["qweight"], r2["data"][k]["qweight"])
+    p1 = float(driver.evaluate_llama(dense, enc, gpu, batch_size=4))
+    p2 = float(driver.evaluate_llama(packed, enc, gpu, batch_size=4))
+    assert abs(p1 - p2) / p1 < 0.02
+
+
+def test_results_round_trip_through_the_reference_file_format(amd, gpu, tmp_path):
+    from gptq_v2_amd import driver
+    model = _tiny_llama(seed=5)
+    enc = torch.randint(0, 512, (8, 64), generator=torch.Generator().manual_seed(4))
+    qmodel = copy.deepcopy(model)
+    res = driver.quantize_llama(qmodel, enc, gpu, batch_size=4)
+    path = str(tmp_path / "quantized.pth")
+    driver.save_results(res, path)
+    loaded = torch.load(path, weights_only=True)
+    assert sorted(loaded) == ["data", "metrics"]
+    for name, meta in res["data"].items():
+        for k, v in meta.items():
+            assert (loaded["data"][name][k] is None) if v is None else torch.equal(loaded["data"][name][k], v), (name, k)
+    dense = driver.load_results_into(copy.deepcopy(model), path, gpu, pack=False)
+    for (n1, p1), (n2, p2) in zip(dense.model.layers.named_parameters(), qmodel.model.layers.named_parameters()):
+        assert torch.equal(p1.data.to(gpu), p2.data.to(gpu)), n1
+    packed = driver.load_results_into(copy.deepcopy(model), path, gpu, pack=True)
+    p_dense = float(driver.evaluate_llama(dense, enc, gpu, batch_size=4))
+    p_packed = float(driver.evaluate_llama(packed, enc, gpu, batch_size=4))
+    assert abs(p_dense - p_packed) / p_dense < 0.02

@@ -9,18 +9,6 @@ from tests.conftest import load_golden, t
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def amd(gpu):
-    import gptq_v2_amd
-    return gptq_v2_amd
-
-
-@pytest.fixture(scope="module")
-def oracle():
-    from oracle import gptq_oracle
-    return gptq_oracle
-
-
 def _bf16(a):
     return t(a, torch.bfloat16)
 
