@@ -17,73 +17,21 @@ struct Prefetch {
     f32x4 v[4];
 };
 
-// k-contiguous source: rows of the tile are rows of the matrix.  BT rows x 32 k = BT/32 passes of
-// 256 threads x 4 floats.
-template <int BT>
-__device__ __forceinline__ void load_kcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
-                                             int n_rows, int k0, int k_hi, int tid)
-{
-    const int kq = (tid & 7) * 4;
-#pragma unroll
-    for (int pass = 0; pass < BT / 32; ++pass) {
-        const int row = row0 + (tid >> 3) + 32 * pass;
-        const int k = k0 + kq;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < n_rows && k < k_hi) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)row * ld + k);
-        p.v[pass] = v;
-    }
-}
-
-template <int BT>
-__device__ __forceinline__ void store_kcontig(const Prefetch &p, float *img, int tid)
-{
-    const int kq = (tid & 7) * 4;
-#pragma unroll
-    for (int pass = 0; pass < BT / 32; ++pass) {
-        float *d = img + ((tid >> 3) + 32 * pass) * 33 + kq;
-        d[0] = p.v[pass][0];
-        d[1] = p.v[pass][1];
-        d[2] = p.v[pass][2];
-        d[3] = p.v[pass][3];
-    }
-}
-
-// row-contiguous source: rows of memory are k, the tile's rows run along memory columns.
-template <int BT>
-__device__ __forceinline__ void load_rcontig(Prefetch &p, const float *__restrict__ src, int64_t ld, int row0,
-                                             int n_rows, int k0, int k_hi, int tid)
-{
-    constexpr int TPR = BT / 4;            // threads per k-row
-    constexpr int KPP = 256 / TPR;         // k-rows per pass
-    const int rq = (tid % TPR) * 4;
-#pragma unroll
-    for (int pass = 0; pass < BT / 32; ++pass) {
-        const int k = k0 + tid / TPR + KPP * pass;
-        const int row = row0 + rq;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < n_rows && k < k_hi) v = *reinterpret_cast<const f32x4 *>(src + (int64_t)k * ld + row);
-        p.v[pass] = v;
-    }
-}
-
-template <int BT>
-__device__ __forceinline__ void store_rcontig(const Prefetch &p, float *img, int tid)
-{
-    constexpr int TPR = BT / 4;
-    constexpr int KPP = 256 / TPR;
-    const int rq = (tid % TPR) * 4;
-#pragma unroll
-    for (int pass = 0; pass < BT / 32; ++pass)
-        *reinterpret_cast<f32x4 *>(img + (tid / TPR + KPP * pass) * BT + rq) = p.v[pass];
-}
-
 // BT x BT output tile per 256-thread workgroup (BT = 128: 2x2 waves of 64x64; BT = 64: 2x2 waves of
 // 32x32, used when the 128-tile grid would leave most CUs idle).  The result does not depend on BT:
 // every element is the same k-ascending chain.
+#ifdef GQ_SG_TRACE
+__device__ unsigned long long *g_sg_trace = nullptr;
+#endif
+
 template <int LAYOUT, int BT>
 __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef GQ_SG_TRACE
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     float *smem = reinterpret_cast<float *>(smem_raw);
     constexpr bool A_KM = (LAYOUT & GQ_A_KM) != 0;
     constexpr bool B_KN = (LAYOUT & GQ_B_KN) != 0;
@@ -145,32 +93,91 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
 
     const float sgn = g.negate ? -1.0f : 1.0f;
     const int n_steps = (k_hi - k_lo + BKS - 1) / BKS;
-    Prefetch pa, pb;
+    constexpr int NP = BT / 32;   // 16-byte pieces per thread and operand
+    // Per-thread source pointers of the pieces, set up once and advanced by a constant per step
+    // (the per-step address arithmetic otherwise delays the first MFMAs of every step); a piece
+    // whose tile row lies outside the matrix is never loaded.
+    const float *pa[NP], *pb[NP];
+    bool oka[NP], okb[NP];
+    int ka[NP], kb[NP];   // first k of the piece at step 0 (for the ragged last step)
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        if constexpr (A_KM) {
+            constexpr int TPR = BT / 4, KPP = 256 / TPR;
+            const int row = m0 + (tid % TPR) * 4, k = k_lo + tid / TPR + KPP * pass;
+            oka[pass] = row < g.m; ka[pass] = k;
+            pa[pass] = g.a + (int64_t)k * g.lda + row;
+        } else {
+            const int row = m0 + (tid >> 3) + 32 * pass, k = k_lo + (tid & 7) * 4;
+            oka[pass] = row < g.m; ka[pass] = k;
+            pa[pass] = g.a + (int64_t)row * g.lda + k;
+        }
+        if constexpr (B_KN) {
+            constexpr int TPR = BT / 4, KPP = 256 / TPR;
+            const int row = n0 + (tid % TPR) * 4, k = k_lo + tid / TPR + KPP * pass;
+            okb[pass] = row < g.n; kb[pass] = k;
+            pb[pass] = g.b + (int64_t)k * g.ldb + row;
+        } else {
+            const int row = n0 + (tid >> 3) + 32 * pass, k = k_lo + (tid & 7) * 4;
+            okb[pass] = row < g.n; kb[pass] = k;
+            pb[pass] = g.b + (int64_t)row * g.ldb + k;
+        }
+    }
+    const int64_t inc_a = A_KM ? (int64_t)BKS * g.lda : BKS, inc_b = B_KN ? (int64_t)BKS * g.ldb : BKS;
+    Prefetch qa, qb;
     auto gload = [&](int step) {
-        const int k0 = k_lo + step * BKS;
-        if constexpr (A_KM) load_rcontig<BT>(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
-        else load_kcontig<BT>(pa, g.a, g.lda, m0, g.m, k0, k_hi, tid);
-        if constexpr (B_KN) load_rcontig<BT>(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
-        else load_kcontig<BT>(pb, g.b, g.ldb, n0, g.n, k0, k_hi, tid);
+        const int koff = step * BKS;
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (oka[pass] && ka[pass] + koff < k_hi) va = *reinterpret_cast<const f32x4 *>(pa[pass]);
+            if (okb[pass] && kb[pass] + koff < k_hi) vb = *reinterpret_cast<const f32x4 *>(pb[pass]);
+            qa.v[pass] = va;
+            qb.v[pass] = vb;
+            pa[pass] += inc_a;
+            pb[pass] += inc_b;
+        }
     };
-    auto lstore = [&](int stage) {
-        float *ia = smem + stage * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
-        if constexpr (A_KM) store_rcontig<BT>(pa, ia, tid);
-        else store_kcontig<BT>(pa, ia, tid);
-        if constexpr (B_KN) store_rcontig<BT>(pb, ib, tid);
-        else store_kcontig<BT>(pb, ib, tid);
+    // piece `pass` of operand A or B into the LDS image of `stage`
+    auto lstore_a = [&](int stage, int pass) {
+        float *ia = smem + stage * STAGE_FLOATS;
+        if constexpr (A_KM) {
+            constexpr int TPR = BT / 4, KPP = 256 / TPR;
+            *reinterpret_cast<f32x4 *>(ia + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = qa.v[pass];
+        } else {
+            float *d = ia + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
+            d[0] = qa.v[pass][0]; d[1] = qa.v[pass][1]; d[2] = qa.v[pass][2]; d[3] = qa.v[pass][3];
+        }
+    };
+    auto lstore_b = [&](int stage, int pass) {
+        float *ib = smem + stage * STAGE_FLOATS + IMG_FLOATS;
+        if constexpr (B_KN) {
+            constexpr int TPR = BT / 4, KPP = 256 / TPR;
+            *reinterpret_cast<f32x4 *>(ib + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = qb.v[pass];
+        } else {
+            float *d = ib + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
+            d[0] = qb.v[pass][0]; d[1] = qb.v[pass][1]; d[2] = qb.v[pass][2]; d[3] = qb.v[pass][3];
+        }
     };
 
     if (n_steps > 0) {
         gload(0);
-        lstore(0);
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            lstore_a(0, pass);
+            lstore_b(0, pass);
+        }
     }
     __syncthreads();
+#ifdef GQ_SG_TRACE
+    const unsigned long long t_loop = __builtin_readcyclecounter();
+#endif
     for (int step = 0; step < n_steps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < n_steps) gload(step + 1);
+        const bool more = step + 1 < n_steps;
+        if (more) gload(step + 1);
         const float *ia = smem + cur * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < BKS / 2; ++s) {
             const int k = 2 * s + lh;
             float fa[WB], fb[WB];
@@ -185,10 +192,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
 #pragma unroll
                 for (int b = 0; b < WB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            // the next step's pieces go to the other LDS stage one at a time in the second half of
+            // the step (their loads are half a step old by then), not in a burst before the barrier
+            if (more && s >= BKS / 2 - 2 * NP) {
+                const int q = s - (BKS / 2 - 2 * NP);
+                if (q & 1) lstore_b(cur ^ 1, q >> 1);
+                else lstore_a(cur ^ 1, q >> 1);
+            }
         }
-        if (step + 1 < n_steps) lstore(cur ^ 1);
         __syncthreads();
     }
+#ifdef GQ_SG_TRACE
+    const unsigned long long t_end = __builtin_readcyclecounter();
+#endif
 
 #pragma unroll
     for (int a = 0; a < WB; ++a)
@@ -200,6 +216,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
                 const int col = n0 + (wc * WB + b) * 32 + li;
                 if (row < g.m && col < g.n) g.c[(int64_t)row * g.ldc + col] = acc[a][b][e];
             }
+#ifdef GQ_SG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g_sg_trace && blockIdx.x == 300 && lane == 0) {
+        unsigned long long *o = g_sg_trace + wave * 8;
+        o[0] = t_begin; o[1] = t_loop; o[2] = t_end; o[3] = __builtin_readcyclecounter(); o[4] = r_begin;
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = n_steps;
+    }
+#endif
 }
 
 template <int BT>
@@ -224,6 +248,14 @@ int launch_sgemm(const GqSgemmArgs &args, hipStream_t stream)
 }
 
 }  // namespace
+
+#ifdef GQ_SG_TRACE
+extern "C" int gq_debug_sg_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sg_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+#endif
 
 int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
 {

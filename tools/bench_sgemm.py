@@ -38,6 +38,18 @@ def run():
             c.zero_(); call(); torch.cuda.synchronize()
             res["check_rel"] = float(((c.double() - ref).abs().max() / ref.abs().max()).item())
     print(json.dumps(res))
+    if hasattr(lib, "gq_debug_sg_trace"):
+        trace = torch.zeros(32, device=dev, dtype=torch.int64)
+        lib.gq_debug_sg_trace(p(trace))
+        m = n = k = 4096
+        a = torch.randn(m, k, device=dev); b = torch.randn(n, k, device=dev); c = torch.zeros(m, n, device=dev)
+        for _ in range(2): lib.gq_debug_sgemm(p(a), p(b), p(c), m, n, k, 0, 0, 0, 0, 0, None)
+        torch.cuda.synchronize()
+        t = trace.cpu().view(4, 8)
+        for w in range(4):
+            T = [int(v) for v in t[w]]
+            print(f"wave {w}: prologue {T[1]-T[0]} loop {T[2]-T[1]} ({(T[2]-T[1])/max(T[6],1):.0f}/step of 32 k; pure MFMA issue 4096) epilogue {T[3]-T[2]} "
+                  f"clock {(T[3]-T[0])/max((T[5]-T[4])*10,1):.2f} GHz")
 
 if __name__ == "__main__":
     build() if sys.argv[1:2] == ["build"] else run()
