@@ -10,6 +10,14 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class GridOptions(ctypes.Structure):
+    """struct gq_grid_options"""
+    _fields_ = [("sym", c_int), ("scale_bits", c_int), ("mse", c_int), ("shrink", c_void_p), ("n_shrink", c_int),
+                ("norm", c_float)]
+
+
 LIB_PATH = os.path.join(_HERE, "lib", "libgptq_amd.so")
 
 # name -> (restype, argtypes); must list every function include/gptq_amd.h declares
@@ -32,6 +40,11 @@ SIGNATURES = {
     "gq_quantize_rtn": (c_int, [c_void_p, c_int, c_int64, c_int64, ctypes.POINTER(ctypes.c_int32),
                                 ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gq_quantize_layer_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64,
+                                     ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), c_int,
+                                     ctypes.POINTER(ctypes.c_int32), c_int, c_int, ctypes.POINTER(GridOptions),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     "gq_quant_metrics": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                  c_void_p]),
     "gq_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p,

@@ -513,6 +513,7 @@ __global__ void rtn_kernel(const float *__restrict__ wt, int64_t r_total, int64_
 
 struct LayerWorkspace {
     float *wt, *scale_g, *zero_g, *error_t;
+    float *qscale_g, *sscale_g;   // EXL2: quantised scales [G][R], their step per group [G]
     uint8_t *q_t;
 };
 
@@ -529,6 +530,8 @@ size_t carve_layer(LayerWorkspace &ws, char *base, int64_t r, int64_t c)
     ws.q_t = (uint8_t *)take((size_t)r * c);
     ws.scale_g = (float *)take((size_t)r * c);   // up to C/4 groups of >= 4 columns, 4 bytes each
     ws.zero_g = (float *)take((size_t)r * c);
+    ws.qscale_g = (float *)take((size_t)r * c);
+    ws.sscale_g = (float *)take((size_t)c);
     return off;
 }
 
@@ -628,6 +631,137 @@ __global__ void find_params_all_kernel(const float *__restrict__ wt, int64_t r_t
     zero_g[g * r_total + r] = zr;
 }
 
+
+// ---- EXL2 scale quantisation and the shrink search ---------------------------------------------
+// quantize2 / dequantize2 (quant.py:40-62): a group's scales on a quadratic grid q^2 * sscale
+__device__ __forceinline__ float quantize2(float x, float s, float smaxq)
+{
+    return clampf(rintf(sqrtf(x / s)), 1.0f, smaxq + 1.0f);
+}
+__device__ __forceinline__ float dequantize2(float q, float s) { return __fmul_rn(__fmul_rn(q, q), s); }
+
+// Quantizer.mse, PyTorch branch, rows (quant.py:151-155): every row tries the candidates
+// scale * shrink[k] and keeps the one with the smallest sum over columns [col0, col0 + ncols) of
+// |dequantize(quantize(x)) - x| ^ norm (first minimum).  The quantisation is the reference's fp32
+// arithmetic; the error sums are accumulated in double, columns ascending.
+// Block (64 rows, 16 candidate slots); slot t takes candidates t, t + 16, ...
+__global__ __launch_bounds__(1024) void mse_rows_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0,
+                                                        int64_t ncols, float maxq, float *__restrict__ scale,
+                                                        const float *__restrict__ zero, const float *__restrict__ shrink,
+                                                        int n_shrink, double norm)
+{
+    __shared__ double best_err[16][64];
+    __shared__ int best_k[16][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int64_t r = (int64_t)blockIdx.x * 64 + tx;
+    const bool live = r < r_total;
+    const int64_t rr = live ? r : r_total - 1;
+    const float s0 = scale[rr], z = zero[rr];
+    double be = 1.0e300 * 1.0e300;   // +inf
+    int bk = 0x7fffffff;
+    for (int k = ty; k < n_shrink; k += 16) {
+        const float sp = __fmul_rn(s0, shrink[k]);
+        double err = 0.0;
+        for (int64_t c = col0; c < col0 + ncols; ++c) {
+            const float x = wt[c * r_total + rr];
+            const float q = clampf(rintf(x / sp) + z, 0.0f, maxq);
+            const float dq = __fmul_rn(__fsub_rn(q, z), sp);
+            err += pow((double)fabsf(__fsub_rn(dq, x)), norm);
+        }
+        if (err < be) {
+            be = err;
+            bk = k;
+        }
+    }
+    best_err[ty][tx] = be;
+    best_k[ty][tx] = bk;
+    __syncthreads();
+    if (ty == 0 && live) {
+        for (int t = 1; t < 16; ++t) {
+            const double e = best_err[t][tx];
+            const int k = best_k[t][tx];
+            if (e < be || (e == be && k < bk)) {
+                be = e;
+                bk = k;
+            }
+        }
+        if (bk != 0x7fffffff) scale[r] = __fmul_rn(s0, shrink[bk]);
+    }
+}
+
+// One workgroup per launch, one group of columns: the group's scales scale[R] go onto the quadratic
+// grid (quant.py:108-112), after an optional search for the best shrink of the grid's step
+// (quant.py:156-165: sum over rows of |dequantize2(quantize2(s)) - s| ^ norm, rows ascending,
+// accumulated in double, first minimum; thread k walks candidate k).
+__global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ scale, float *__restrict__ qscale,
+                                                         float *__restrict__ sscale_out, int64_t r_total, float smaxq,
+                                                         int search, const float *__restrict__ shrink, int n_shrink,
+                                                         double norm)
+{
+    __shared__ float red[256];
+    __shared__ double cand_err[256];
+    __shared__ float ss_shared;
+    const int tid = threadIdx.x;
+    float m = -3.4e38f;
+    for (int64_t r = tid; r < r_total; r += 256) m = fmaxf(m, scale[r]);
+    red[tid] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] = fmaxf(red[tid], red[tid + w]);
+        __syncthreads();
+    }
+    const float full = smaxq + 1.0f;
+    float ss = red[0] / __fmul_rn(full, full) + 1e-12f;
+    if (search) {
+        double err = 1.0e300 * 1.0e300;
+        if (tid < n_shrink) {
+            const float sp = __fmul_rn(ss, shrink[tid]);
+            err = 0.0;
+            for (int64_t r = 0; r < r_total; ++r) {
+                const float x = scale[r];
+                const float d = __fsub_rn(dequantize2(quantize2(x, sp, smaxq), sp), x);
+                err += pow((double)fabsf(d), norm);
+            }
+        }
+        cand_err[tid] = err;
+        __syncthreads();
+        if (tid == 0) {
+            int bk = 0;
+            double be = cand_err[0];
+            for (int k = 1; k < n_shrink && k < 256; ++k)
+                if (cand_err[k] < be) {
+                    be = cand_err[k];
+                    bk = k;
+                }
+            ss_shared = __fmul_rn(ss, shrink[bk]);
+        }
+        __syncthreads();
+        ss = ss_shared;
+    }
+    for (int64_t r = tid; r < r_total; r += 256) {
+        const float q = quantize2(scale[r], ss, smaxq);
+        qscale[r] = q;
+        scale[r] = dequantize2(q, ss);
+    }
+    if (tid == 0) *sscale_out = ss;
+}
+
+// qscale_g [G][R] fp32 -> qscale [R][G] uint8, sscale_g [G] fp32 -> sscale [G] (weight dtype)
+template <int DTYPE>
+__global__ void collate_exl2_kernel(const float *__restrict__ qscale_g, const float *__restrict__ sscale_g, int64_t r_total,
+                                    int n_groups, uint8_t *__restrict__ qscale, unsigned short *__restrict__ sscale)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups) {
+        const float s = sscale_g[i];
+        if constexpr (DTYPE == GQ_F16) sscale[i] = __builtin_bit_cast(unsigned short, (_Float16)s);
+        else sscale[i] = __builtin_bit_cast(unsigned short, (__bf16)s);
+    }
+    if (i >= r_total * n_groups) return;
+    const int64_t g = i / r_total, r = i - g * r_total;
+    qscale[r * n_groups + g] = (uint8_t)qscale_g[i];
+}
+
 }  // namespace
 
 extern "C" int gq_find_params(const float *weights_t, int64_t c, int64_t r, int64_t col0, int64_t ncols, int bits,
@@ -677,106 +811,214 @@ extern "C" size_t gq_quantize_layer_workspace(int64_t r, int64_t c)
     return carve_layer(ws, nullptr, r, c);
 }
 
-extern "C" int gq_quantize_layer(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
-                                 int64_t r, int64_t c, const int32_t *group_sizes_host,
-                                 const int32_t *group_bits_host, int n_groups, int sym, int semantics,
-                                 uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t, float *error_t,
-                                 void *workspace, size_t workspace_bytes, gq_stream_t stream_)
+namespace {
+
+// One launch of the block kernel: columns [s0, s1) of group g.
+struct Launch { int64_t s0, s1; int g; };
+// A run of launches between two points where a grid may be computed from the working weights:
+// one launch (static grids) or one of the reference's blocks (dynamic grids).  `need_end`: the grids
+// computed at the start of this unit read the working weights up to this column.
+struct Unit { size_t first, last; int64_t col0, col1, need_end; int g_first, g_last; };
+
+int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, const float *u, int64_t r, int64_t c,
+                        const int32_t *gs, const int32_t *gb, int n_groups, const int32_t *bs, int n_blocks,
+                        int semantics, const gq_grid_options &o, uint8_t *qweight, void *scale, uint8_t *qzero,
+                        uint8_t *qscale, void *sscale, float *quant_t, float *error_t, void *workspace,
+                        size_t workspace_bytes, hipStream_t stream, const char *who)
 {
-    GQ_REQUIRE(weight && hessian_inv && qweight && scale && qzero && workspace, "gq_quantize_layer: NULL pointer");
-    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quantize_layer: bad dtype %d", dtype);
-    GQ_REQUIRE(semantics == GQ_SEM_KERNEL || semantics == GQ_SEM_PYTHON, "gq_quantize_layer: bad semantics %d", semantics);
-    GQ_REQUIRE(r > 0 && c > 0 && r % 4 == 0, "gq_quantize_layer: out_features %lld must be a positive multiple of 4", (long long)r);
-    GQ_REQUIRE(r <= (1 << 22) && c <= (1 << 22), "gq_quantize_layer: at most 2^22 rows and columns");
-    int rc = check_groups(group_sizes_host, group_bits_host, n_groups, c, "gq_quantize_layer");
+    GQ_REQUIRE(weight && qweight && scale && qzero && workspace, "%s: NULL pointer", who);
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: bad dtype %d", who, dtype);
+    GQ_REQUIRE(semantics == GQ_SEM_KERNEL || semantics == GQ_SEM_PYTHON, "%s: bad semantics %d", who, semantics);
+    GQ_REQUIRE(r > 0 && c > 0, "%s: bad shape", who);
+    GQ_REQUIRE(!u || r % 4 == 0, "%s: out_features %lld must be a multiple of 4", who, (long long)r);
+    GQ_REQUIRE(r <= (1 << 22) && c <= (1 << 22), "%s: at most 2^22 rows and columns", who);
+    GQ_REQUIRE(u || !perm, "%s: a column permutation needs a Hessian factor", who);
+    int rc = check_groups(gs, gb, n_groups, c, who);
     if (rc) return rc;
-    if (semantics == GQ_SEM_PYTHON)   // the grid is computed inside the block kernel: one block per group
-        for (int g = 0; g < n_groups; ++g)
-            GQ_REQUIRE(group_sizes_host[g] == block_size_for(group_sizes_host[g]),
-                       "gq_quantize_layer: python semantics supports groups of 4, 8 or 16..128 (multiple of 16) columns, got %d", group_sizes_host[g]);
+    const bool exl2 = o.scale_bits > 0;
+    GQ_REQUIRE(o.scale_bits >= 0 && o.scale_bits <= 8, "%s: scale_bits %d (0..8 supported)", who, o.scale_bits);
+    GQ_REQUIRE(!exl2 || (qscale && sscale), "%s: scale quantisation needs the qscale and sscale outputs", who);
+    GQ_REQUIRE(!o.mse || (o.shrink && o.n_shrink >= 1 && o.n_shrink <= 256 && o.norm > 0.0f),
+               "%s: the shrink search needs 1..256 candidates and a positive norm", who);
+    const int sym = (o.sym || exl2) ? 1 : 0;
+    const float smaxq = exl2 ? (float)((1 << o.scale_bits) - 1) : 0.0f;
+
     LayerWorkspace ws;
     const size_t need = carve_layer(ws, (char *)workspace, r, c);
     if (workspace_bytes < need) {
-        gq_set_error("gq_quantize_layer: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        gq_set_error("%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, need);
         return GQ_EWORKSPACE;
     }
-    hipStream_t stream = (hipStream_t)stream_;
     float *err = error_t ? error_t : ws.error_t;
+    std::vector<int64_t> gstart(n_groups + 1, 0);
+    for (int g = 0; g < n_groups; ++g) gstart[g + 1] = gstart[g] + gs[g];
 
     rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, r, c, ws.wt, stream)
                          : launch_prep<GQ_BF16>(weight, perm, r, c, ws.wt, stream);
     if (rc) return rc;
 
-    if (semantics == GQ_SEM_KERNEL) {   // grid of every group from the unmodified weights
-        bool uniform = true;
-        for (int g = 1; g < n_groups; ++g)
-            uniform = uniform && group_sizes_host[g] == group_sizes_host[0] && group_bits_host[g] == group_bits_host[0];
-        if (uniform) {
-            dim3 grid((unsigned)gq_cdiv(r, 256), (unsigned)n_groups);
-            hipLaunchKernelGGL(find_params_all_kernel, grid, dim3(256), 0, stream, ws.wt, r, (int)group_sizes_host[0],
-                               (float)((1 << group_bits_host[0]) - 1), sym, ws.scale_g, ws.zero_g);
+    // grid of group g from the working weights as they are now (quant.py:89-118), refined over
+    // columns [m0, m0 + mn) if the shrink search is on (quant.py:120-165)
+    auto grid_for_group = [&](int g, int64_t m0, int64_t mn) -> int {
+        const float maxq = (float)((1 << gb[g]) - 1);
+        float *sg = ws.scale_g + (int64_t)g * r, *zg = ws.zero_g + (int64_t)g * r, *qg = ws.qscale_g + (int64_t)g * r;
+        hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, gstart[g],
+                           (int64_t)gs[g], maxq, sym, sg, zg);
+        GQ_LAUNCH_CHECK();
+        if (exl2) {
+            hipLaunchKernelGGL(exl2_scale_kernel, dim3(1), dim3(256), 0, stream, sg, qg, ws.sscale_g + g, r, smaxq, 0,
+                               (const float *)nullptr, 0, 0.0);
             GQ_LAUNCH_CHECK();
-        } else {
-            int64_t col = 0;
-            for (int g = 0; g < n_groups; ++g) {
-                const float maxq = (float)((1 << group_bits_host[g]) - 1);
-                hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, col,
-                                   (int64_t)group_sizes_host[g], maxq, sym, ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r);
+        }
+        if (o.mse) {
+            hipLaunchKernelGGL(mse_rows_kernel, dim3((unsigned)gq_cdiv(r, 64)), dim3(64, 16), 0, stream, ws.wt, r, m0, mn, maxq,
+                               sg, zg, o.shrink, o.n_shrink, (double)o.norm);
+            GQ_LAUNCH_CHECK();
+            if (exl2) {
+                hipLaunchKernelGGL(exl2_scale_kernel, dim3(1), dim3(256), 0, stream, sg, qg, ws.sscale_g + g, r, smaxq, 1,
+                                   o.shrink, o.n_shrink, (double)o.norm);
                 GQ_LAUNCH_CHECK();
-                col += group_sizes_host[g];
             }
         }
-    }
+        return GQ_OK;
+    };
+    const bool plain_grid = !exl2 && !o.mse;
 
-    // Blocks of <= 128 columns, never across a group boundary, gathered into super-blocks of about
-    // SUPER columns: after each block only the columns up to the end of its super-block are updated
-    // (short GEMM, K = block), the columns behind the super-block once per super-block (K = SUPER).
-    // Each weight still receives its updates in ascending column order.
-    struct Blk { int64_t s0, s1; int g; };
-    std::vector<Blk> blocks;
-    {
-        int64_t col = 0;
+    if (!u) {   // round to nearest (gptq_py.py:101-124)
+        const unsigned rg = (unsigned)gq_cdiv(r, 256);
         for (int g = 0; g < n_groups; ++g) {
-            const int64_t gend = col + group_sizes_host[g];
-            for (int64_t s0 = col, s1; s0 < gend; s0 = s1) {
-                s1 = s0 + block_size_for(gend - s0);
-                blocks.push_back({s0, s1, g});
+            if ((rc = grid_for_group(g, gstart[g], gs[g]))) return rc;
+            hipLaunchKernelGGL(rtn_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, gstart[g], (int64_t)gs[g],
+                               (float)((1 << gb[g]) - 1), ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r, ws.q_t, quant_t);
+            GQ_LAUNCH_CHECK();
+        }
+    } else {
+        // The reference's blocks: its native loop works group by group (gptq_py.py:132-144), its
+        // PyTorch loop block by block (gptq_py.py:162-193).
+        std::vector<int64_t> bstart;
+        if (semantics == GQ_SEM_KERNEL || !bs) {
+            bstart = gstart;
+        } else {
+            GQ_REQUIRE(n_blocks > 0, "%s: block description missing", who);
+            bstart.assign(1, 0);
+            for (int b = 0; b < n_blocks; ++b) {
+                GQ_REQUIRE(bs[b] > 0 && bs[b] % 4 == 0, "%s: block %d has size %d (must be a positive multiple of 4)", who, b, bs[b]);
+                bstart.push_back(bstart.back() + bs[b]);
             }
-            col = gend;
+            GQ_REQUIRE(bstart.back() == c, "%s: block sizes sum to %lld, in_features is %lld", who,
+                       (long long)bstart.back(), (long long)c);
         }
-    }
-    constexpr int64_t SUPER = 512;
-    for (size_t i = 0; i < blocks.size();) {
-        size_t j = i;
-        const int64_t sup0 = blocks[i].s0;
-        while (j < blocks.size() && blocks[j].s1 - sup0 < SUPER) ++j;
-        const size_t last = std::min(j, blocks.size() - 1);
-        const int64_t sup1 = blocks[last].s1;
-        for (size_t b = i; b <= last; ++b) {
-            const Blk &bk = blocks[b];
-            QuantBlockArgs p{};
-            p.wt = ws.wt; p.quant_t = quant_t; p.error_t = err; p.q_out = ws.q_t; p.u = hessian_inv;
-            p.scale = ws.scale_g + (int64_t)bk.g * r; p.zero = ws.zero_g + (int64_t)bk.g * r;
-            p.c = c; p.r = r; p.a = (int)bk.s0; p.bs = (int)(bk.s1 - bk.s0);
-            p.maxq = (float)((1 << group_bits_host[bk.g]) - 1);
-            p.q_is_u8 = 1; p.write_back = 0; p.dynamic = semantics == GQ_SEM_PYTHON; p.sym = sym;
-            if ((rc = launch_block(p, semantics, stream))) return rc;
-            if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, bk.s0, bk.s1, bk.s1, sup1, stream))) return rc;
+        // dynamic grids computed inside the block kernel: one launch per block == group
+        bool in_kernel_grid = semantics == GQ_SEM_PYTHON && plain_grid && bstart == gstart;
+        for (int g = 0; in_kernel_grid && g < n_groups; ++g) in_kernel_grid = gs[g] == block_size_for(gs[g]);
+
+        // launches: a block cut at group boundaries, then into register-sized pieces
+        std::vector<Launch> launches;
+        std::vector<Unit> units;
+        {
+            int g = 0;
+            for (size_t b = 0; b + 1 < bstart.size(); ++b) {
+                const int64_t i1 = bstart[b], i2 = bstart[b + 1];
+                Unit un{launches.size(), 0, i1, i2, i2, n_groups, -1};
+                for (int64_t s0 = i1, s1; s0 < i2; s0 = s1) {
+                    while (gstart[g + 1] <= s0) ++g;
+                    if (gstart[g] == s0) {   // this group's grid is due at the start of the block (gptq_py.py:169-186)
+                        un.g_first = std::min(un.g_first, g);
+                        un.g_last = g;
+                        un.need_end = std::max(un.need_end, gstart[g + 1]);
+                    }
+                    s1 = s0 + block_size_for(std::min(i2, gstart[g + 1]) - s0);
+                    launches.push_back({s0, s1, g});
+                }
+                un.last = launches.size() - 1;
+                if (semantics == GQ_SEM_KERNEL) {   // static grids: every launch may end a super-block
+                    for (size_t l = un.first; l <= un.last; ++l)
+                        units.push_back({l, l, launches[l].s0, launches[l].s1, launches[l].s1, n_groups, -1});
+                } else {
+                    units.push_back(un);
+                }
+            }
         }
-        if ((rc = trailing_update(hessian_inv, ws.wt, err, c, r, sup0, sup1, sup1, c, stream))) return rc;
-        i = last + 1;
+
+        if (semantics == GQ_SEM_KERNEL) {   // grid of every group from the unmodified weights
+            bool uniform = plain_grid;
+            for (int g = 1; g < n_groups; ++g) uniform = uniform && gs[g] == gs[0] && gb[g] == gb[0];
+            if (uniform) {
+                dim3 grid((unsigned)gq_cdiv(r, 256), (unsigned)n_groups);
+                hipLaunchKernelGGL(find_params_all_kernel, grid, dim3(256), 0, stream, ws.wt, r, (int)gs[0],
+                                   (float)((1 << gb[0]) - 1), sym, ws.scale_g, ws.zero_g);
+                GQ_LAUNCH_CHECK();
+            } else {
+                for (int g = 0; g < n_groups; ++g)
+                    if ((rc = grid_for_group(g, gstart[g], gs[g]))) return rc;
+            }
+        }
+
+        // Units are gathered into super-blocks of about SUPER columns: after each launch only the
+        // columns up to the super-block's eager end are updated (short GEMM, K = launch), the columns
+        // behind it once per super-block (K = SUPER).  Each weight still receives its updates in
+        // ascending column order.  The eager end covers every column a grid computed inside the
+        // super-block reads, so those grids see all earlier updates.
+        constexpr int64_t SUPER = 512;
+        for (size_t i = 0; i < units.size();) {
+            size_t j = i;
+            const int64_t sup0 = units[i].col0;
+            while (j < units.size() && units[j].col1 - sup0 < SUPER) ++j;
+            const size_t last = std::min(j, units.size() - 1);
+            const int64_t kend = units[last].col1;
+            int64_t eager = kend;
+            for (size_t k = i; k <= last; ++k) eager = std::max(eager, units[k].need_end);
+            for (size_t k = i; k <= last; ++k) {
+                const Unit &un = units[k];
+                if (semantics == GQ_SEM_PYTHON && !in_kernel_grid)
+                    for (int g = un.g_first; g <= un.g_last; ++g)   // the search looks at the block (gptq_py.py:178-179)
+                        if ((rc = grid_for_group(g, un.col0, un.col1 - un.col0))) return rc;
+                for (size_t l = un.first; l <= un.last; ++l) {
+                    const Launch &la = launches[l];
+                    QuantBlockArgs p{};
+                    p.wt = ws.wt; p.quant_t = quant_t; p.error_t = err; p.q_out = ws.q_t; p.u = u;
+                    p.scale = ws.scale_g + (int64_t)la.g * r; p.zero = ws.zero_g + (int64_t)la.g * r;
+                    p.c = c; p.r = r; p.a = (int)la.s0; p.bs = (int)(la.s1 - la.s0);
+                    p.maxq = (float)((1 << gb[la.g]) - 1);
+                    p.q_is_u8 = 1; p.write_back = 0; p.dynamic = in_kernel_grid; p.sym = sym;
+                    if ((rc = launch_block(p, semantics, stream))) return rc;
+                    if ((rc = trailing_update(u, ws.wt, err, c, r, la.s0, la.s1, la.s1, eager, stream))) return rc;
+                }
+            }
+            if ((rc = trailing_update(u, ws.wt, err, c, r, sup0, kend, eager, c, stream))) return rc;
+            i = last + 1;
+        }
     }
 
     dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
     hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
     GQ_LAUNCH_CHECK();
     const unsigned cg = (unsigned)gq_cdiv(r * n_groups, 256);
-    if (dtype == GQ_F16)
+    if (dtype == GQ_F16) {
         hipLaunchKernelGGL(collate_grid_kernel<GQ_F16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
-    else
+        if (exl2) hipLaunchKernelGGL(collate_exl2_kernel<GQ_F16>, dim3(cg), dim3(256), 0, stream, ws.qscale_g, ws.sscale_g, r, n_groups, qscale, (unsigned short *)sscale);
+    } else {
         hipLaunchKernelGGL(collate_grid_kernel<GQ_BF16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
+        if (exl2) hipLaunchKernelGGL(collate_exl2_kernel<GQ_BF16>, dim3(cg), dim3(256), 0, stream, ws.qscale_g, ws.sscale_g, r, n_groups, qscale, (unsigned short *)sscale);
+    }
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+}  // namespace
+
+extern "C" int gq_quantize_layer(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                                 int64_t r, int64_t c, const int32_t *group_sizes_host,
+                                 const int32_t *group_bits_host, int n_groups, int sym, int semantics,
+                                 uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t, float *error_t,
+                                 void *workspace, size_t workspace_bytes, gq_stream_t stream_)
+{
+    GQ_REQUIRE(hessian_inv, "gq_quantize_layer: NULL pointer");
+    gq_grid_options o{};
+    o.sym = sym;
+    return quantize_layer_impl(weight, dtype, perm, hessian_inv, r, c, group_sizes_host, group_bits_host, n_groups, nullptr,
+                               0, semantics, o, qweight, scale, qzero, nullptr, nullptr, quant_t, error_t, workspace,
+                               workspace_bytes, (hipStream_t)stream_, "gq_quantize_layer");
 }
 
 extern "C" int gq_quantize_rtn(const void *weight, int dtype, int64_t r, int64_t c, const int32_t *group_sizes_host,
@@ -784,42 +1026,24 @@ extern "C" int gq_quantize_rtn(const void *weight, int dtype, int64_t r, int64_t
                                uint8_t *qzero, float *quant_t, void *workspace, size_t workspace_bytes,
                                gq_stream_t stream_)
 {
-    GQ_REQUIRE(weight && qweight && scale && qzero && workspace, "gq_quantize_rtn: NULL pointer");
-    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quantize_rtn: bad dtype %d", dtype);
-    GQ_REQUIRE(r > 0 && c > 0, "gq_quantize_rtn: bad shape");
-    int rc = check_groups(group_sizes_host, group_bits_host, n_groups, c, "gq_quantize_rtn");
-    if (rc) return rc;
-    LayerWorkspace ws;
-    const size_t need = carve_layer(ws, (char *)workspace, r, c);
-    if (workspace_bytes < need) {
-        gq_set_error("gq_quantize_rtn: workspace of %zu bytes, %zu needed", workspace_bytes, need);
-        return GQ_EWORKSPACE;
-    }
-    hipStream_t stream = (hipStream_t)stream_;
-    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, nullptr, r, c, ws.wt, stream)
-                         : launch_prep<GQ_BF16>(weight, nullptr, r, c, ws.wt, stream);
-    if (rc) return rc;
-    int64_t col = 0;
-    const unsigned rg = (unsigned)gq_cdiv(r, 256);
-    for (int g = 0; g < n_groups; ++g) {
-        const float maxq = (float)((1 << group_bits_host[g]) - 1);
-        float *sg = ws.scale_g + (int64_t)g * r, *zg = ws.zero_g + (int64_t)g * r;
-        hipLaunchKernelGGL(find_params_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, col, (int64_t)group_sizes_host[g], maxq, sym, sg, zg);
-        GQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rtn_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, col, (int64_t)group_sizes_host[g], maxq, sg, zg, ws.q_t, quant_t);
-        GQ_LAUNCH_CHECK();
-        col += group_sizes_host[g];
-    }
-    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
-    hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
-    GQ_LAUNCH_CHECK();
-    const unsigned cg = (unsigned)gq_cdiv(r * n_groups, 256);
-    if (dtype == GQ_F16)
-        hipLaunchKernelGGL(collate_grid_kernel<GQ_F16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
-    else
-        hipLaunchKernelGGL(collate_grid_kernel<GQ_BF16>, dim3(cg), dim3(256), 0, stream, ws.scale_g, ws.zero_g, r, n_groups, (unsigned short *)scale, qzero);
-    GQ_LAUNCH_CHECK();
-    return GQ_OK;
+    gq_grid_options o{};
+    o.sym = sym;
+    return quantize_layer_impl(weight, dtype, nullptr, nullptr, r, c, group_sizes_host, group_bits_host, n_groups, nullptr, 0,
+                               GQ_SEM_KERNEL, o, qweight, scale, qzero, nullptr, nullptr, quant_t, nullptr, workspace,
+                               workspace_bytes, (hipStream_t)stream_, "gq_quantize_rtn");
+}
+
+extern "C" int gq_quantize_layer_ex(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                                    int64_t r, int64_t c, const int32_t *group_sizes_host,
+                                    const int32_t *group_bits_host, int n_groups, const int32_t *block_sizes_host,
+                                    int n_blocks, int semantics, const gq_grid_options *options, uint8_t *qweight,
+                                    void *scale, uint8_t *qzero, uint8_t *qscale, void *sscale, float *quant_t,
+                                    float *error_t, void *workspace, size_t workspace_bytes, gq_stream_t stream_)
+{
+    GQ_REQUIRE(options, "gq_quantize_layer_ex: NULL options");
+    return quantize_layer_impl(weight, dtype, perm, hessian_inv, r, c, group_sizes_host, group_bits_host, n_groups,
+                               block_sizes_host, n_blocks, semantics, *options, qweight, scale, qzero, qscale, sscale, quant_t,
+                               error_t, workspace, workspace_bytes, (hipStream_t)stream_, "gq_quantize_layer_ex");
 }
 
 extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,

@@ -110,15 +110,19 @@ def gptq_quant_set(
     input-sharing set, which the reference quantises one after the other (llama.py:150-170).
     Same arguments and, per weight, the same result dictionary as ``gptq_quant``; the work of all
     of them is enqueued on side streams before anything is waited for."""
-    if scale_bit_width is not None:
-        raise NotImplementedError("EXL2 scale quantisation (scale_bit_width) is not supported")
-    if quant_mse:
-        raise NotImplementedError("quant_mse grid search is not supported (llama.py runs with quant_mse=False)")
+    if quant_mse and quant_use_kernel:
+        raise NotImplementedError("quant_use_kernel=True calls exllamav2_ext, which the reference does not import "
+                                  "either (quant.py:4)")
     gs = _group_list(group_sizes)
     gb = _group_list(group_bit_widths)
+    scale_bits = 0 if scale_bit_width is None else int(scale_bit_width)
+    blocks = None
     if hessian_hook is not None and not gptq_use_kernel:
-        if gptq_block_sizes is None or _group_list(gptq_block_sizes) != gs:
-            raise NotImplementedError("the PyTorch-loop semantics are implemented for gptq_block_sizes == group_sizes")
+        if gptq_block_sizes is None:
+            raise ValueError("the PyTorch-loop semantics need gptq_block_sizes")
+        blocks = _group_list(gptq_block_sizes)
+        if blocks == gs:
+            blocks = None
     weights = list(weights)
     if not weights:
         return []
@@ -132,12 +136,15 @@ def gptq_quant_set(
         # gptq_py.py:95-96 zeroes columns whose Hessian diagonal is 0; after invert() no diagonal
         # entry is 0 any more (dead ones were set to 1, then damped), so nothing is zeroed there either.
     sem = ops.SEM_KERNEL if gptq_use_kernel else ops.SEM_PYTHON
+    shrink = None
+    if quant_mse:   # the candidates exactly as the reference builds them (quant.py:151), on the host
+        shrink = (1.0 - torch.arange(0.0, quant_max_shrink, 1.0 / quant_n_grid)).to(device)
 
     main = torch.cuda.current_stream(device)
     side = _side_streams(device)
     for st in side:
         st.wait_stream(main)   # inputs were produced on the caller's stream; earlier results of ours were read there
-    per_weight = ROW_SLICES
+    per_weight = 1 if scale_bits > 0 else ROW_SLICES   # the step of a group's scale grid is a maximum over all rows
     jobs = []   # (weight index, row range, result tensors, metric sums)
     k = 0
     for wi, weight in enumerate(weights):
@@ -145,7 +152,8 @@ def gptq_quant_set(
         for b, e in _row_slices(w.shape[0], per_weight):
             with torch.cuda.stream(side[k % len(side)]):
                 res = ops.quantize_layer(w[b:e], perm32, u, gs, gb, sym=quant_symmetric, semantics=sem,
-                                         want_quant=True, want_error=hessian_hook is not None)
+                                         want_quant=True, want_error=hessian_hook is not None, block_sizes=blocks,
+                                         scale_bits=scale_bits, shrink=shrink, norm=quant_norm)
                 sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"])
             jobs.append((wi, res, sums))
             k += 1
@@ -172,16 +180,41 @@ def gptq_quant_set(
             perm_inv = hessian_hook.perm_inv.to(torch.int16)
         else:
             perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
+        qweight, scale, qzero = cat("qweight"), cat("scale"), cat("qzero")
+        qscale = sscale = sbw = None
+        out_gs, out_gb = list(gs), list(gb)
+        if scale_bit_width is not None:
+            # gptq_py.py:202-229: with scale quantisation the groups are stored widest first (bit width,
+            # then size, descending; earlier groups first among equals) and the column order follows
+            order = sorted(range(len(gs)), key=lambda g: (gb[g], gs[g], -g), reverse=True)
+            sbw = torch.as_tensor(scale_bit_width).to(dtype=torch.uint8, device=save_device)
+            if scale_bits > 0:
+                qscale, sscale = cat("qscale"), mine[0][1]["sscale"]
+            if order != list(range(len(gs))):
+                starts = [0]
+                for v in gs:
+                    starts.append(starts[-1] + v)
+                idx_g = torch.tensor(order, dtype=torch.int64, device=device)
+                idx_c = torch.cat([torch.arange(starts[g], starts[g + 1], device=device) for g in order])
+                qweight, scale, qzero = qweight[:, idx_c], scale[:, idx_g], qzero[:, idx_g]
+                if qscale is not None:
+                    qscale, sscale = qscale[:, idx_g], sscale[idx_g]
+                perm = hessian_hook.perm if perm32 is not None else torch.arange(n_columns, device=device)
+                stored = perm[idx_c]   # stored column j holds original column stored[j]
+                perm_inv = torch.empty(n_columns, dtype=torch.int64, device=device)
+                perm_inv[stored] = torch.arange(n_columns, device=device)
+                perm_inv = perm_inv.to(torch.int16)
+                out_gs, out_gb = [gs[g] for g in order], [gb[g] for g in order]
         quant_meta = {
-            "qweight": cat("qweight").to(device=save_device),
-            "scale": cat("scale").to(device=save_device),
-            "qzero": cat("qzero").to(device=save_device),
-            "qscale": None,
-            "sscale": None,
+            "qweight": qweight.to(device=save_device),
+            "scale": scale.to(device=save_device),
+            "qzero": qzero.to(device=save_device),
+            "qscale": None if qscale is None else qscale.to(device=save_device),
+            "sscale": None if sscale is None else sscale.to(device=save_device),
             "perm_inv": perm_inv.to(device=save_device),
-            "group_sizes": torch.as_tensor(gs, dtype=torch.int16, device=save_device),
-            "group_bit_widths": torch.as_tensor(gb, dtype=torch.uint8, device=save_device),
-            "scale_bit_width": None,
+            "group_sizes": torch.as_tensor(out_gs, dtype=torch.int16, device=save_device),
+            "group_bit_widths": torch.as_tensor(out_gb, dtype=torch.uint8, device=save_device),
+            "scale_bit_width": sbw,
         }
         out.append({"quant_meta": quant_meta, "metrics": metrics})
     return out
@@ -204,7 +237,8 @@ def gptq_quant(
         quant_use_kernel: bool = False,
         save_device: torch.device = torch.device('cpu'),
 ) -> dict:
-    """gptq_py.py:69-251.  ``gptq_use_kernel=True`` selects the semantics of the reference's
+    """gptq_py.py:69-251 with all of its knobs (mixed groups, ``scale_bit_width``, ``quant_mse``,
+    ``gptq_block_sizes``).  ``gptq_use_kernel=True`` selects the semantics of the reference's
     native loop (grid from the unmodified weights, fp16 dequantisation), ``False`` those of its
     pure-PyTorch loop (grid from the error-compensated weights, fp32 dequantisation);
     ``hessian_hook=None`` rounds to nearest.  Returns {'quant_meta': ..., 'metrics': ...}."""

@@ -126,9 +126,14 @@ def quantize_range(quant, scale, out_q, qzero, maxq, hessian_inv, weights, error
 
 def quantize_layer(weight: torch.Tensor, perm: Optional[torch.Tensor], hessian_inv: Optional[torch.Tensor],
                    group_sizes: Sequence[int], group_bits: Sequence[int], sym: bool = False,
-                   semantics: int = SEM_KERNEL, want_quant: bool = True, want_error: bool = True):
+                   semantics: int = SEM_KERNEL, want_quant: bool = True, want_error: bool = True,
+                   block_sizes: Optional[Sequence[int]] = None, scale_bits: int = 0,
+                   shrink: Optional[torch.Tensor] = None, norm: float = 2.4):
     """weight (R, C) fp16/bf16 -> dict(qweight u8 (R,C), scale (R,G) weight dtype, qzero u8 (R,G),
-    quant_t fp32 (C,R) | None, error_t fp32 (C,R) | None).  hessian_inv None = round to nearest."""
+    qscale u8 (R,G) | None, sscale (G,) weight dtype | None, quant_t fp32 (C,R) | None,
+    error_t fp32 (C,R) | None).  hessian_inv None = round to nearest.
+    block_sizes: the PyTorch loop's blocks (None = the groups); scale_bits > 0: EXL2 scale
+    quantisation; shrink: device tensor of shrink candidates, switches the error-minimising search on."""
     _check(weight, "weight", None, 2)
     code = _dtype_code(weight)
     r, c = weight.shape
@@ -140,28 +145,45 @@ def quantize_layer(weight: torch.Tensor, perm: Optional[torch.Tensor], hessian_i
     qweight = torch.empty(r, c, dtype=torch.uint8, device=dev)
     scale = torch.empty(r, g, dtype=weight.dtype, device=dev)
     qzero = torch.empty(r, g, dtype=torch.uint8, device=dev)
+    qscale = torch.empty(r, g, dtype=torch.uint8, device=dev) if scale_bits > 0 else None
+    sscale = torch.empty(g, dtype=weight.dtype, device=dev) if scale_bits > 0 else None
     quant_t = torch.empty(c, r, dtype=torch.float32, device=dev) if want_quant else None
+    error_t = None
+    if hessian_inv is not None:
+        _check(hessian_inv, "hessian_inv", torch.float32, 2)
+        if hessian_inv.shape != (c, c):
+            raise RuntimeError("H shape mismatch")
+        if perm is not None:
+            _check(perm, "perm", torch.int32, 1)
+        error_t = torch.empty(c, r, dtype=torch.float32, device=dev) if want_error else None
+    if shrink is not None:
+        _check(shrink, "shrink", torch.float32, 1)
     ws_bytes = lib.gq_quantize_layer_workspace(r, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     gs, gb = _int_array(group_sizes), _int_array(group_bits)
+    extended = block_sizes is not None or scale_bits > 0 or shrink is not None
     with torch.cuda.device(dev):
-        if hessian_inv is None:
-            error_t = None
+        if extended:
+            opt = _lib.GridOptions(int(sym), int(scale_bits), int(shrink is not None),
+                                   shrink.data_ptr() if shrink is not None else None,
+                                   shrink.numel() if shrink is not None else 0, float(norm))
+            bsz = _int_array(block_sizes) if block_sizes is not None else None
+            rc = lib.gq_quantize_layer_ex(_p(weight), code, _p(perm), _p(hessian_inv), r, c, gs, gb, g, bsz,
+                                          len(block_sizes) if block_sizes is not None else 0, int(semantics),
+                                          ctypes.byref(opt), _p(qweight), _p(scale), _p(qzero), _p(qscale), _p(sscale),
+                                          _p(quant_t), _p(error_t), _p(ws), ws_bytes, _stream(weight))
+            _lib.check(rc, "gq_quantize_layer_ex")
+        elif hessian_inv is None:
             rc = lib.gq_quantize_rtn(_p(weight), code, r, c, gs, gb, g, int(sym), _p(qweight), _p(scale), _p(qzero),
                                      _p(quant_t), _p(ws), ws_bytes, _stream(weight))
             _lib.check(rc, "gq_quantize_rtn")
         else:
-            _check(hessian_inv, "hessian_inv", torch.float32, 2)
-            if hessian_inv.shape != (c, c):
-                raise RuntimeError("H shape mismatch")
-            if perm is not None:
-                _check(perm, "perm", torch.int32, 1)
-            error_t = torch.empty(c, r, dtype=torch.float32, device=dev) if want_error else None
             rc = lib.gq_quantize_layer(_p(weight), code, _p(perm), _p(hessian_inv), r, c, gs, gb, g, int(sym),
                                        int(semantics), _p(qweight), _p(scale), _p(qzero), _p(quant_t), _p(error_t),
                                        _p(ws), ws_bytes, _stream(weight))
             _lib.check(rc, "gq_quantize_layer")
-    return {"qweight": qweight, "scale": scale, "qzero": qzero, "quant_t": quant_t, "error_t": error_t}
+    return {"qweight": qweight, "scale": scale, "qzero": qzero, "qscale": qscale, "sscale": sscale,
+            "quant_t": quant_t, "error_t": error_t}
 
 
 def quant_metrics(weight, perm, hessian_inv, quant_t, error_t) -> torch.Tensor:

@@ -5,13 +5,14 @@ Same names, argument meaning and result types as the reference (quant.py:10-30, 
 have: it reconstructs a dense fp16 ``nn.Linear`` (llama.py:172-177) where this module can also run
 the packed int4 x fp16 GEMM.
 
-Not mirrored: the EXL2 quadratic scale quantisation (quantize2 / dequantize2 / construct_matrix_2,
-quant.py:40-69, 240-259) and ``Quantizer.mse`` (quant.py:120-165); the reference's driver switches
-both off (llama.py:153, 157) and asking for them here raises NotImplementedError.
+The EXL2 quadratic scale quantisation (quantize2 / dequantize2 / construct_matrix_2, quant.py:40-69,
+240-259) and ``Quantizer.mse`` (quant.py:120-165, its PyTorch branch; the other one calls an
+extension the reference itself does not import, quant.py:4) are mirrored too; the reference's driver
+switches both off (llama.py:153, 157).
 
-The element-wise helpers below work on tensors of any device, as the reference's do; the hot
-paths (gptq_quant's loops, reconstruct_nn_linear, QuantLinear) go through libgptq_amd.so and
-require a GPU.
+The element-wise helpers and ``Quantizer`` below are plain tensor arithmetic on whatever device the
+tensors live on, as the reference's are; the hot paths (gptq_quant's loops with their grids,
+reconstruct_nn_linear, QuantLinear) go through libgptq_amd.so and require a GPU.
 """
 from __future__ import annotations
 
@@ -39,36 +40,83 @@ def dequantize_quantized(x, scale, qzero, maxq):
     return dequantize(quantize(x, scale, qzero, maxq), scale, qzero)
 
 
+def quantize2(x: torch.Tensor, scale: torch.Tensor, maxq) -> torch.Tensor:
+    """Quadratic quantisation of positive numbers (a column of scales, EXL2): the level q in
+    1..maxq+1 with q^2 * scale nearest in the square-root domain (quant.py:40-51)."""
+    return torch.clamp(torch.round(torch.sqrt(x / scale)), 1.0, maxq + 1.0)
+
+
+def dequantize2(qx: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """qx^2 * scale (quant.py:54-62)."""
+    return qx * qx * scale
+
+
+def dequantize2_quantized2(x, scale, maxq):
+    return dequantize2(quantize2(x, scale, maxq), scale)
+
+
 class Quantizer:
-    """Per-row quantisation grid over the last dimension (quant.py:72-183)."""
+    """Per-row quantisation grid over the last dimension (quant.py:72-183); with
+    ``scale_bit_width`` the scales themselves sit on a quadratic grid ``qscale^2 * sscale``."""
 
     def __init__(self, scale: torch.Tensor = None, qzero: torch.Tensor = None, maxq=None,
                  qscale=None, sscale=None, smaxq=None):
-        if qscale is not None or sscale is not None or smaxq is not None:
-            raise NotImplementedError("EXL2 scale quantisation (qscale/sscale) is not supported")
-        self.scale = scale
-        self.qzero = qzero
-        self.maxq = maxq
-        self.qscale = None
-        self.sscale = None
-        self.smaxq = None
+        self.scale = scale      # (..., R, 1)
+        self.qzero = qzero      # (..., R, 1)
+        self.maxq = maxq        # ()
+        self.qscale = qscale    # (..., R, 1)
+        self.sscale = sscale    # (..., 1, 1)
+        self.smaxq = smaxq      # ()
+        # quant.py:84-87: whichever of scale / qscale is missing follows from the other
+        if scale is None and qscale is not None and sscale is not None:
+            self.scale = dequantize2(qscale, sscale)
+        elif qscale is None and scale is not None and sscale is not None and smaxq is not None:
+            self.qscale = quantize2(scale, sscale, smaxq)
+
+    def _requantize_scale(self) -> None:
+        self.qscale = quantize2(self.scale, self.sscale, self.smaxq)
+        self.scale = dequantize2(self.qscale, self.sscale)
+
+    def _sscale_from_scale(self) -> torch.Tensor:
+        return self.scale.amax(dim=-2, keepdim=True) / (self.smaxq + 1.0) ** 2.0 + EPSILON
 
     def find_params(self, x: torch.Tensor, bit_width, sym: bool = False, scale_bit_width=None) -> None:
-        if scale_bit_width is not None and scale_bit_width > 0:
-            raise NotImplementedError("EXL2 scale quantisation (scale_bit_width) is not supported")
+        """quant.py:89-118.  bit_width / scale_bit_width: 0-dim tensors (or numbers)."""
+        exl2 = scale_bit_width is not None and scale_bit_width > 0
         self.maxq = 2.0 ** bit_width - 1.0
-        if sym:
+        if sym or exl2:
             self.scale = x.abs().amax(dim=-1, keepdim=True) * (2.0 / self.maxq) + EPSILON
             mid = torch.round(torch.as_tensor((self.maxq + 1.0) * 0.5))
             self.qzero = torch.full_like(self.scale, float(mid))
+            if exl2:
+                self.smaxq = 2.0 ** scale_bit_width - 1.0
+                self.sscale = self._sscale_from_scale()
+                self._requantize_scale()
         else:
             hi = torch.relu(x.amax(dim=-1, keepdim=True))
             lo = -torch.relu(-x.amin(dim=-1, keepdim=True))
             self.scale = (hi - lo) / self.maxq + EPSILON
             self.qzero = torch.round(-lo / self.scale)
 
-    def mse(self, *args, **kwargs) -> None:
-        raise NotImplementedError("Quantizer.mse grid search is not supported (llama.py runs with quant_mse=False)")
+    def mse(self, x: torch.Tensor, max_shrink: float = .8, n_grid: int = 100, norm: float = 2.4,
+            use_kernel: bool = False) -> None:
+        """Shrinks every row's scale to the candidate with the smallest |error|^norm summed over the
+        row, then (EXL2) does the same for the step of the scale grid (quant.py:120-165)."""
+        if use_kernel:
+            raise NotImplementedError("Quantizer.mse(use_kernel=True) calls exllamav2_ext, which the reference does "
+                                      "not import either (quant.py:4)")
+        p = 1.0 - torch.arange(0.0, max_shrink, 1.0 / n_grid, device=x.device)   # (Q)
+        xq = x[..., None]
+        cand = dequantize_quantized(xq, self.scale[..., None] * p, self.qzero[..., None], self.maxq)   # (..., R, C, Q)
+        best = (cand - xq).abs().pow(norm).sum(dim=-2).argmin(dim=-1, keepdim=True)
+        self.scale = self.scale * p[best]
+        if self.sscale is not None:
+            self.sscale = self._sscale_from_scale()
+            sq = self.scale[..., None]
+            cand = dequantize2_quantized2(sq, self.sscale[..., None] * p, self.smaxq)   # (..., R, 1, Q)
+            best = (cand - sq).abs().pow(norm).sum(dim=-3).argmin(dim=-1, keepdim=True)
+            self.sscale = self.sscale * p[best]
+            self._requantize_scale()
 
     def quantize(self, x):
         return quantize(x, self.scale, self.qzero, self.maxq)
@@ -109,9 +157,30 @@ def construct_matrix(qweight: torch.Tensor, scale: torch.Tensor, qzero: torch.Te
                           qz.to(device=dev, dtype=torch.uint8).contiguous(), None, gs)
 
 
+def exl2_scale(qscale: torch.Tensor, sscale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(R, G) scales of an EXL2 ``quant_meta`` as the reference evaluates them when it rebuilds the
+    weight (quant.py:84-85 with the operand types of quant.py:267-268): the squared level as an
+    int16, times the group's step in ``dtype``."""
+    q = qscale.to(torch.int16)
+    return (q * q) * sscale.to(dtype).reshape(1, -1)
+
+
+def construct_matrix_2(qweight: torch.Tensor, qzero: torch.Tensor, qscale: torch.Tensor, sscale: torch.Tensor,
+                       group_sizes: torch.Tensor) -> torch.Tensor:
+    """construct_matrix for EXL2 metadata: scale = qscale^2 * sscale (quant.py:240-259)."""
+    return construct_matrix(qweight, exl2_scale(qscale, sscale, sscale.dtype), qzero, group_sizes)
+
+
+def meta_scale(quant_meta: dict, dtype: torch.dtype, device) -> torch.Tensor:
+    """The (R, G) scales reconstruct_nn_linear dequantises with (quant.py:266-272)."""
+    if quant_meta.get("sscale") is not None:
+        return exl2_scale(quant_meta["qscale"].to(device), quant_meta["sscale"].to(device), dtype).contiguous()
+    return quant_meta["scale"].to(device=device, dtype=dtype).contiguous()
+
+
 def reconstruct_weight(quant_meta: dict, dtype: torch.dtype, device) -> torch.Tensor:
     qweight = quant_meta["qweight"].to(device=device, dtype=torch.uint8).contiguous()
-    scale = quant_meta["scale"].to(device=device, dtype=dtype).contiguous()
+    scale = meta_scale(quant_meta, dtype, device)
     qzero = quant_meta["qzero"].to(device=device, dtype=torch.uint8).contiguous()
     gs = _group_list(quant_meta["group_sizes"])
     perm_inv = quant_meta.get("perm_inv")
@@ -123,8 +192,6 @@ def reconstruct_weight(quant_meta: dict, dtype: torch.dtype, device) -> torch.Te
 def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.device = None) -> nn.Linear:
     """Dense ``nn.Linear`` (no bias) from a ``quant_meta`` dict (quant.py:262-279).  The
     dequantisation runs on the GPU, so ``device`` must be a GPU (the reference defaults to CPU)."""
-    if quant_meta.get("sscale") is not None:
-        raise NotImplementedError("EXL2 quant_meta (sscale/qscale) is not supported")
     if device is None:
         device = quant_meta["qweight"].device
     weight = reconstruct_weight(quant_meta, dtype, device)
@@ -176,7 +243,7 @@ class QuantLinear(nn.Module):
         if self.in_features % 64:
             raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
         self.qweight = ops.pack_rows(q, self.bits, ops.PACK_W4_KBLOCK)
-        self.scales = quant_meta["scale"].to(device=device, dtype=torch.float16).t().contiguous()
+        self.scales = meta_scale(quant_meta, torch.float16, device).t().contiguous()
         self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
         perm_inv = quant_meta.get("perm_inv")
         if perm_inv is None:

@@ -77,7 +77,7 @@ int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t
 /* Per-row quantisation grid over columns [col0, col0+ncols) of W^T stored as weights_t[C][R]:
  * asymmetric (sym = 0): scale = (max(x,0) - min(x,0)) / maxq + 1e-12, qzero = round(-min/scale);
  * symmetric: scale = max|x| * 2/maxq + 1e-12, qzero = (maxq+1)/2.   maxq = 2^bits - 1.
- * ref: quant.py:89-118 (without the EXL2 scale quantisation). */
+ * ref: quant.py:89-118 (the EXL2 scale quantisation: gq_quantize_layer_ex). */
 int gq_find_params(const float *weights_t, int64_t c, int64_t r, int64_t col0, int64_t ncols, int bits,
                    int sym, float *scale, float *qzero, gq_stream_t stream);
 
@@ -106,6 +106,45 @@ int gq_quantize_layer(const void *weight, int dtype, const int32_t *perm, const 
                       const int32_t *group_bits_host, int n_groups, int sym, int semantics,
                       uint8_t *qweight, void *scale, uint8_t *qzero, float *quant_t, float *error_t,
                       void *workspace, size_t workspace_bytes, gq_stream_t stream);
+
+/* How the per-group grids are chosen in gq_quantize_layer_ex. */
+typedef struct gq_grid_options {
+    int sym;             /* symmetric grid (ref: quant.py:104-106); implied by scale_bits > 0 */
+    int scale_bits;      /* 0: off.  1..8: EXL2 scale quantisation -- a group's scales go onto the
+                            quadratic grid q^2 * sscale, q in 1..2^scale_bits, sscale one number per
+                            group (ref: quant.py:40-69, 108-112) */
+    int mse;             /* != 0: Quantizer.mse, PyTorch branch (ref: quant.py:150-165): every row keeps
+                            the candidate scale * shrink[k] with the smallest sum of
+                            |dequantize(quantize(x)) - x|^norm (first minimum; with scale_bits > 0 the
+                            same search is then run for sscale over the group's rows).  The
+                            quantisation is fp32 as in the reference; the error sums are accumulated
+                            in double where the reference sums fp32 powers, so a near-tie may be
+                            decided differently */
+    const float *shrink; /* DEVICE array of the n_shrink candidates; the reference's are
+                            1 - arange(0, max_shrink, 1 / n_grid) */
+    int n_shrink;        /* 1..256 */
+    float norm;          /* > 0 */
+} gq_grid_options;
+
+/* gq_quantize_layer with the reference's remaining knobs.
+ *   hessian_inv == NULL: round to nearest (perm must be NULL, semantics is ignored).
+ *   block_sizes_host / n_blocks: the blocks of the PyTorch loop (GQ_SEM_PYTHON only; NULL = the
+ *     groups).  As in the reference, a group's grid is computed when the loop reaches the group's
+ *     first column, from the weights as they were at the start of the block that column lies in,
+ *     and the shrink search looks at the columns of that block (ref: gptq_py.py:162-186); for
+ *     GQ_SEM_KERNEL every grid comes from the unmodified weights and the search looks at the
+ *     group's own columns (ref: gptq_py.py:132-139).
+ *   qscale uint8 [R][G] and sscale [G] (weight dtype) are written when options->scale_bits > 0
+ *     (and must then be non-NULL); scale then holds q^2 * sscale.
+ * Groups are reported in column order; the reference's re-ordering of mixed groups
+ * (gptq_py.py:202-229) is index arithmetic left to the caller.
+ * ref: gptq_py.py:69-251, quant.py:89-165. */
+int gq_quantize_layer_ex(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
+                         int64_t r, int64_t c, const int32_t *group_sizes_host,
+                         const int32_t *group_bits_host, int n_groups, const int32_t *block_sizes_host,
+                         int n_blocks, int semantics, const gq_grid_options *options, uint8_t *qweight,
+                         void *scale, uint8_t *qzero, uint8_t *qscale, void *sscale, float *quant_t,
+                         float *error_t, void *workspace, size_t workspace_bytes, gq_stream_t stream);
 
 /* Round-to-nearest quantisation without a Hessian (same outputs as gq_quantize_layer;
  * error is identically zero in the reference and is not produced).

@@ -10,8 +10,9 @@ It restates, on CPU tensors, what the reference's Python layer computes
   here                   reference
   =====================  ==========================================================
   OracleHessian          gptq_py.py:9-66     HessianHook.add_batch(use_kernel=False), invert
-  find_params            quant.py:89-118     Quantizer.find_params (min/max and symmetric grids)
-  quantize / dequantize  quant.py:10-30
+  find_params            quant.py:89-118     Quantizer.find_params (min/max, symmetric and EXL2 grids)
+  quantize / dequantize  quant.py:10-30      (+ quantize2 / dequantize2, quant.py:40-69)
+  mse_refine             quant.py:120-165    Quantizer.mse, PyTorch branch
   quantize_range_kernel  package/gptq/gptq_cpp.cpp:33-84 + gptq_cpp_kernel.cu:21-137
                          (through the C restatement ``kernel_path_ref.c``)
   gptq_quant             gptq_py.py:69-251   all three branches + result collation
@@ -145,19 +146,85 @@ def dequantize(qx, scale, qzero):
     return (qx - qzero) * scale  # quant.py:30
 
 
-def find_params(x: torch.Tensor, bit_width, sym: bool = False):
-    """x (..., R, C) -> scale, qzero of shape (..., R, 1), maxq scalar.  quant.py:102-118
-    without the EXL2 scale-quantisation branch (switched off by llama.py:153)."""
-    maxq = 2.0 ** bit_width - 1.0
-    if sym:
-        scale = x.abs().amax(dim=-1, keepdim=True) * (2.0 / maxq) + EPSILON
-        qzero = torch.full_like(scale, float(torch.round(torch.as_tensor((maxq + 1.0) * 0.5))))
+def quantize2(x, scale, maxq):
+    return torch.clamp(torch.round(torch.sqrt(x / scale)), 1.0, maxq + 1.0)  # quant.py:51
+
+
+def dequantize2(qx, scale):
+    return qx * qx * scale  # quant.py:62
+
+
+class Grid:
+    """One group's grid: scale, qzero (R, 1), maxq; EXL2: qscale (R, 1), sscale (1, 1), smaxq."""
+
+    def __init__(self):
+        self.scale = self.qzero = self.maxq = self.qscale = self.sscale = self.smaxq = None
+
+
+def find_params(x: torch.Tensor, bit_width, sym: bool = False, scale_bit_width=None, full: bool = False):
+    """x (..., R, C) -> scale, qzero of shape (..., R, 1), maxq scalar (or the whole Grid with
+    ``full``).  quant.py:99-118; every operand fp32 as in the reference (bit widths are tensors
+    there, so 2 ** bit_width is an fp32 tensor)."""
+    g = Grid()
+    exl2 = scale_bit_width is not None and int(scale_bit_width) > 0
+    g.maxq = torch.tensor(2.0, dtype=torch.float32) ** int(bit_width) - 1.0
+    if sym or exl2:
+        g.scale = x.abs().amax(dim=-1, keepdim=True) * (2.0 / g.maxq) + EPSILON
+        g.qzero = torch.full_like(g.scale, float(torch.round((g.maxq + 1.0) * 0.5)))
+        if exl2:
+            g.smaxq = torch.tensor(2.0, dtype=torch.float32) ** int(scale_bit_width) - 1.0
+            g.sscale = g.scale.amax(dim=-2, keepdim=True) / (g.smaxq + 1.0) ** 2.0 + EPSILON
+            g.qscale = quantize2(g.scale, g.sscale, g.smaxq)
+            g.scale = dequantize2(g.qscale, g.sscale)
     else:
         hi = torch.relu(x.amax(dim=-1, keepdim=True))
         lo = -torch.relu(-x.amin(dim=-1, keepdim=True))
-        scale = (hi - lo) / maxq + EPSILON
-        qzero = torch.round(-lo / scale)
-    return scale, qzero, maxq
+        g.scale = (hi - lo) / g.maxq + EPSILON
+        g.qzero = torch.round(-lo / g.scale)
+    if full:
+        return g
+    return g.scale, g.qzero, float(g.maxq)
+
+
+def shrink_candidates(max_shrink: float = 0.8, n_grid: int = 100) -> torch.Tensor:
+    return 1.0 - torch.arange(0.0, max_shrink, 1.0 / n_grid)  # quant.py:151
+
+
+def _first_argmin(err: torch.Tensor) -> torch.Tensor:
+    """index of the first minimum along the last dimension, keepdim"""
+    best = err.min(dim=-1, keepdim=True).values
+    q = err.shape[-1]
+    idx = torch.where(err == best, torch.arange(q).expand(err.shape), torch.full(err.shape, q))
+    return idx.min(dim=-1, keepdim=True).values
+
+
+def mse_refine(g: Grid, x: torch.Tensor, max_shrink: float = 0.8, n_grid: int = 100, norm: float = 2.4,
+               exact: bool = False) -> None:
+    """Quantizer.mse, PyTorch branch (quant.py:151-165), in place on ``g``.
+    exact=False: the reference's arithmetic (fp32 powers summed by torch).
+    exact=True: the same candidates with the powers and sums in float64 and the first minimum
+    taken -- the definition the HIP kernel follows; it differs from the above only where two
+    candidates' errors agree to fp32 rounding."""
+    p = shrink_candidates(max_shrink, n_grid)
+
+    def pick(cand, ref, dim):
+        d = (cand - ref).abs()
+        if exact:
+            return _first_argmin(d.to(torch.float64).pow(norm).sum(dim=dim))
+        return d.pow(norm).sum(dim=dim).argmin(dim=-1, keepdim=True)
+
+    xq = x[..., None]
+    sp = g.scale[..., None] * p
+    cand = dequantize(quantize(xq, sp, g.qzero[..., None], g.maxq), sp, g.qzero[..., None])
+    g.scale = g.scale * p[pick(cand, xq, -2)]
+    if g.sscale is not None:
+        g.sscale = g.scale.amax(dim=-2, keepdim=True) / (g.smaxq + 1.0) ** 2.0 + EPSILON
+        sq = g.scale[..., None]
+        ssp = g.sscale[..., None] * p
+        cand = dequantize2(quantize2(sq, ssp, g.smaxq), ssp)
+        g.sscale = g.sscale * p[pick(cand, sq, -3)]
+        g.qscale = quantize2(g.scale, g.sscale, g.smaxq)
+        g.scale = dequantize2(g.qscale, g.sscale)
 
 
 # ---------------------------------------------------------------------------------------
@@ -200,10 +267,11 @@ def xtx_accumulate_exact(hessian: torch.Tensor, x: torch.Tensor) -> None:
 @torch.no_grad()
 def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes: torch.Tensor,
                group_bit_widths: torch.Tensor, use_kernel_semantics: bool = True,
-               block_sizes: Optional[torch.Tensor] = None, symmetric: bool = False) -> dict:
+               block_sizes: Optional[torch.Tensor] = None, symmetric: bool = False,
+               scale_bit_width=None, mse: bool = False, max_shrink: float = 0.8, n_grid: int = 100,
+               norm: float = 2.4, mse_exact: bool = False) -> dict:
     """Returns {'quant_meta': {...}, 'metrics': {...}, 'debug': {...}} with quant_meta and
-    metrics as in gptq_py.py:240-251 (mse search and EXL2 scales are not restated: the
-    driver switches both off, llama.py:153,157)."""
+    metrics as in gptq_py.py:240-251."""
     n_rows, n_cols = weight.shape
     dtype = weight.dtype
     w_ref = weight
@@ -214,18 +282,23 @@ def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes:
         dead = hook.hessian.diagonal() == 0.0  # gptq_py.py:95-96 (a no-op after invert)
         w[:, dead] = 0.0
     bounds = [0] + torch.cumsum(group_sizes, 0).tolist()
-    scales, zeros = [], []
+    grids = []
     debug: dict = {}
+
+    def new_grid(cols: torch.Tensor, bw, search_cols: torch.Tensor) -> Grid:
+        g = find_params(cols, bw, symmetric, scale_bit_width, full=True)
+        if mse:
+            mse_refine(g, search_cols, max_shrink, n_grid, norm, exact=mse_exact)
+        grids.append(g)
+        return g
 
     if hook is None:  # gptq_py.py:101-124 round to nearest
         quant = torch.empty_like(w)
         qweight = torch.empty_like(w)
         for bw, i1, i2 in zip(group_bit_widths.tolist(), bounds[:-1], bounds[1:]):
-            s, z, mq = find_params(w[:, i1:i2], bw, symmetric)
-            scales.append(s)
-            zeros.append(z)
-            qweight[:, i1:i2] = quantize(w[:, i1:i2], s, z, mq)
-            quant[:, i1:i2] = dequantize(qweight[:, i1:i2], s, z)
+            g = new_grid(w[:, i1:i2], bw, w[:, i1:i2])
+            qweight[:, i1:i2] = quantize(w[:, i1:i2], g.scale, g.qzero, g.maxq)
+            quant[:, i1:i2] = dequantize(qweight[:, i1:i2], g.scale, g.qzero)
         error = torch.zeros((), dtype=torch.float32)
     elif use_kernel_semantics:  # gptq_py.py:125-157
         w_t = w.t().contiguous()
@@ -234,10 +307,8 @@ def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes:
         q_t = torch.empty_like(w_t, dtype=torch.int16)
         u = hook.hessian_inv.contiguous()
         for bw, i1, i2 in zip(group_bit_widths.tolist(), bounds[:-1], bounds[1:]):
-            s, z, mq = find_params(w[:, i1:i2], bw, symmetric)  # grid from the UNMODIFIED weights
-            scales.append(s)
-            zeros.append(z)
-            quantize_range_kernel(quant_t, s[:, 0].contiguous(), q_t, z[:, 0].contiguous(), float(mq),
+            g = new_grid(w[:, i1:i2], bw, w[:, i1:i2])  # grid from the UNMODIFIED weights
+            quantize_range_kernel(quant_t, g.scale[:, 0].contiguous(), q_t, g.qzero[:, 0].contiguous(), float(g.maxq),
                                   u, w_t, error_t, i1, i2)
         quant, qweight, error = quant_t.t(), q_t.t().to(torch.float32), error_t.t()
         debug = {"weight_t": w_t, "quant_t": quant_t, "error_t": error_t}
@@ -248,20 +319,19 @@ def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes:
         qweight = torch.empty_like(w)
         error = torch.empty_like(w)
         bbounds = [0] + torch.cumsum(block_sizes, 0).tolist()
-        g = 0
-        s = z = mq = None
+        gi = 0
+        g = None
         for i1, i2 in zip(bbounds[:-1], bbounds[1:]):
             blk = w[:, i1:i2].clone()
             eblk = torch.empty_like(blk)
             for j in range(i1, i2):
-                if j == bounds[g]:
-                    s, z, mq = find_params(w[:, j:j + int(group_sizes[g])], int(group_bit_widths[g]), symmetric)
-                    scales.append(s)
-                    zeros.append(z)
-                    g += 1
+                if gi < len(bounds) - 1 and j == bounds[gi]:
+                    # the grid sees w as it was when the block began; the search looks at the block
+                    g = new_grid(w[:, j:j + int(group_sizes[gi])], int(group_bit_widths[gi]), w[:, i1:i2])
+                    gi += 1
                 col = blk[:, j - i1:j - i1 + 1]
-                qc = quantize(col, s, z, mq)
-                dq = dequantize(qc, s, z)
+                qc = quantize(col, g.scale, g.qzero, g.maxq)
+                dq = dequantize(qc, g.scale, g.qzero)
                 e = (col - dq) / u[j, j]
                 qweight[:, j:j + 1] = qc
                 quant[:, j:j + 1] = dq
@@ -275,27 +345,38 @@ def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes:
         "gptq_norm": float(((w_ref / hook.hessian_inv.diagonal()) ** 2.0).mean()) if hook is not None
         else float((error ** 2.0).mean()),
     }
-    # gptq_py.py:216-229 with scale_bit_width None: groups keep their order
-    scale = torch.cat(scales, dim=-1).to(dtype)
-    qzero = torch.cat(zeros, dim=-1).to(torch.uint8)
+    # gptq_py.py:202-229: with scale quantisation the groups are stored sorted by
+    # (bit width, size, -index), descending; otherwise in place
+    n_groups = len(group_sizes)
+    order = list(range(n_groups))
+    if scale_bit_width is not None:
+        order.sort(key=lambda k: (int(group_bit_widths[k]), int(group_sizes[k]), -k), reverse=True)
+    idx_c = torch.cat([torch.arange(bounds[k], bounds[k + 1]) for k in order])
+    idx_g = torch.tensor(order, dtype=torch.int64)
+    exl2 = grids[0].qscale is not None
+    scale = torch.cat([g.scale for g in grids], dim=-1).to(dtype)[:, idx_g]
+    qzero = torch.cat([g.qzero for g in grids], dim=-1).to(torch.uint8)[:, idx_g]
+    qscale = torch.cat([g.qscale for g in grids], dim=-1).to(torch.uint8)[:, idx_g] if exl2 else None
+    sscale = torch.cat([g.sscale for g in grids], dim=-1).to(dtype)[0, idx_g] if exl2 else None
     if hook is not None and hook.perm is not None:
-        perm = hook.perm.to(torch.int16)
+        perm = hook.perm.to(torch.int16)[idx_c]
     else:
-        perm = torch.arange(n_cols, dtype=torch.int16)
+        perm = torch.arange(n_cols, dtype=torch.int16)[idx_c]
     perm_inv = torch.argsort(perm).to(torch.int16)
-    quant_unperm = quant[:, perm_inv.to(torch.int32)]
+    quant_sorted = quant[:, idx_c]
+    quant_unperm = quant_sorted[:, perm_inv.to(torch.int32)]
     metrics["l2.0_error"] = float(((quant_unperm.float() - w_ref.float()).abs() ** 2.0).mean())
     metrics["l2.0_norm"] = float((w_ref.abs() ** 2.0).mean())
     meta = {
-        "qweight": qweight.to(torch.uint8).contiguous(),
+        "qweight": qweight.to(torch.uint8)[:, idx_c].contiguous(),
         "scale": scale.contiguous(),
         "qzero": qzero.contiguous(),
-        "qscale": None,
-        "sscale": None,
+        "qscale": qscale,
+        "sscale": sscale,
         "perm_inv": perm_inv,
-        "group_sizes": group_sizes.to(torch.int16),
-        "group_bit_widths": group_bit_widths.to(torch.uint8),
-        "scale_bit_width": None,
+        "group_sizes": group_sizes.to(torch.int16)[idx_g],
+        "group_bit_widths": group_bit_widths.to(torch.uint8)[idx_g],
+        "scale_bit_width": None if scale_bit_width is None else torch.as_tensor(scale_bit_width).to(torch.uint8),
     }
     debug["quant"] = quant
     return {"quant_meta": meta, "metrics": metrics, "debug": debug}
@@ -309,7 +390,11 @@ def construct_weight(meta: dict, dtype: torch.dtype = torch.float16, unpermute: 
     """(int16 q - int16 z) * scale evaluated in ``dtype`` per group, then columns un-permuted."""
     q = meta["qweight"].to(torch.int16)
     z = meta["qzero"].to(torch.int16)
-    s = meta["scale"].to(dtype)
+    if meta.get("sscale") is not None:  # quant.py:266-269, 84-85: int16 level squared times the step in `dtype`
+        qs = meta["qscale"].to(torch.int16)
+        s = (qs * qs) * meta["sscale"].to(dtype).reshape(1, -1)
+    else:
+        s = meta["scale"].to(dtype)
     bounds = [0] + torch.cumsum(meta["group_sizes"].to(torch.int64), 0).tolist()
     w = torch.empty(q.shape, dtype=dtype)
     for k, (i1, i2) in enumerate(zip(bounds[:-1], bounds[1:])):

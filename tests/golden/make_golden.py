@@ -152,13 +152,15 @@ def f3_find_params():
     save("f3_find_params", **out)
 
 
-def quant_case(tag, r, c, bits, seed, use_kernel, act_order=True, with_hook=True):
+def quant_case(tag, r, c, bits, seed, use_kernel, act_order=True, with_hook=True, group_sizes=None, group_bits=None,
+               block_sizes=None, scale_bits=None, mse=False, sym=False):
     gen = torch.Generator().manual_seed(seed)
     w = (torch.randn(r, c, generator=gen) * 0.02).to(torch.float16)
     x = calib(gen, 4, max(96, c // 2), c)
-    g = c // 128
-    gs = torch.full([g], 128, dtype=torch.int32)
-    gb = torch.full([g], bits, dtype=torch.int32)
+    gs = torch.tensor(group_sizes, dtype=torch.int32) if group_sizes else torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.tensor(group_bits, dtype=torch.int32) if group_bits else torch.full([len(gs)], bits, dtype=torch.int32)
+    bs = torch.tensor(block_sizes, dtype=torch.int32) if block_sizes else gs
+    sbw = None if scale_bits is None else torch.tensor(scale_bits, dtype=torch.int32)
     hook = None
     extra = {}
     if with_hook:
@@ -168,18 +170,42 @@ def quant_case(tag, r, c, bits, seed, use_kernel, act_order=True, with_hook=True
         extra = dict(h_raw=h_raw, n_samples=np.int64(hook.n_samples), hessian_inv=hook.hessian_inv,
                      perm=hook.perm)
     res = ref_gptq.gptq_quant(weight=w, hessian_hook=hook, group_sizes=gs, group_bit_widths=gb,
-                              scale_bit_width=None, gptq_use_kernel=use_kernel, gptq_block_sizes=gs,
-                              quant_symmetric=False, quant_mse=False, save_device=torch.device("cpu"))
+                              scale_bit_width=sbw, gptq_use_kernel=use_kernel, gptq_block_sizes=bs,
+                              quant_symmetric=sym, quant_mse=mse, save_device=torch.device("cpu"))
     meta, metrics = res["quant_meta"], res["metrics"]
     lin = ref_quant.reconstruct_nn_linear(meta, dtype=torch.float16)
     xin = (torch.randn(8, c, generator=gen)).to(torch.float16)
     y = lin(xin)
-    save(tag, w=w, group_sizes=gs, group_bit_widths=gb, act_order=np.bool_(act_order),
+    save(tag, w=w, group_sizes=gs, group_bit_widths=gb, block_sizes=bs, act_order=np.bool_(act_order),
+         sym=np.bool_(sym), mse=np.bool_(mse), scale_bits=None if scale_bits is None else np.int64(scale_bits),
          qweight=meta["qweight"], scale=meta["scale"], qzero=meta["qzero"], perm_inv=meta["perm_inv"],
+         qscale=meta["qscale"], sscale=meta["sscale"],
          meta_group_sizes=meta["group_sizes"], meta_group_bit_widths=meta["group_bit_widths"],
          metrics=np.array([metrics["gptq_error"], metrics["gptq_norm"], metrics["l2.0_error"],
                            metrics["l2.0_norm"]], dtype=np.float64),
          recon_weight=lin.weight.data, lin_x=xin, lin_y=y, **extra)
+
+
+def f9_grid_options():
+    """Quantizer.find_params with scale quantisation and Quantizer.mse on their own."""
+    gen = torch.Generator().manual_seed(909)
+    w = torch.randn(48, 96, generator=gen) * 0.02
+    w[0] = 0.0
+    w[1, :] = 0.25
+    out = {"w": w}
+    for bits, sbw, mse in ((4, 4, False), (3, 4, True), (4, None, True), (4, 6, True)):
+        q = ref_quant.Quantizer()
+        q.find_params(w, bit_width=torch.tensor(bits), sym=False,
+                      scale_bit_width=None if sbw is None else torch.tensor(sbw))
+        if mse:
+            q.mse(w)
+        tag = f"b{bits}_s{sbw}_{'mse' if mse else 'nomse'}"
+        out[f"scale_{tag}"] = q.scale
+        out[f"qzero_{tag}"] = q.qzero
+        if sbw is not None:
+            out[f"qscale_{tag}"] = q.qscale
+            out[f"sscale_{tag}"] = q.sscale
+    save("f9_grid_options", **out)
 
 
 def main():
@@ -194,6 +220,20 @@ def main():
     quant_case("f5_kernelsem_128x384_b3", 128, 384, 3, 405, use_kernel=True)
     quant_case("f5_kernelsem_64x256_b4_noact", 64, 256, 4, 406, use_kernel=True, act_order=False)
     quant_case("f7_rtn_64x256_b4", 64, 256, 4, 407, use_kernel=False, with_hook=False)
+    # the knobs the reference's driver leaves off: shrink search, scale quantisation with mixed
+    # groups (their stored order is sorted), PyTorch-loop blocks that differ from the groups
+    quant_case("f8_kernelsem_mse_64x256_b4", 64, 256, 4, 408, use_kernel=True, mse=True)
+    quant_case("f8_kernelsem_exl2_64x256_mixed", 64, 256, 4, 409, use_kernel=True, mse=True, scale_bits=4,
+               group_sizes=[64, 128, 32, 32], group_bits=[3, 4, 4, 3])
+    quant_case("f8_kernelsem_exl2_nomse_64x256", 64, 256, 4, 410, use_kernel=True, scale_bits=4)
+    quant_case("f8_pysem_blocks128_g64_64x256", 64, 256, 4, 411, use_kernel=False, group_sizes=[64] * 4,
+               block_sizes=[128, 128])
+    quant_case("f8_pysem_blocks64_g128_64x256", 64, 256, 4, 412, use_kernel=False, block_sizes=[64] * 4)
+    quant_case("f8_pysem_mse_exl2_64x256", 64, 256, 4, 413, use_kernel=False, mse=True, scale_bits=4,
+               group_sizes=[64] * 4, block_sizes=[128, 128])
+    quant_case("f8_rtn_mse_exl2_64x256", 64, 256, 4, 414, use_kernel=False, with_hook=False, mse=True, scale_bits=4,
+               group_sizes=[128, 128], group_bits=[3, 4])
+    f9_grid_options()
 
 
 if __name__ == "__main__":

@@ -165,3 +165,79 @@ def test_pack_roundtrip(bits, n):
     if bits == 4:
         w0 = int(p[0, 0]) & 0xFFFFFFFF
         assert [(w0 >> (4 * i)) & 15 for i in range(8)] == v[0, :8].tolist()
+
+
+# ---- the knobs the reference's driver leaves off (mse search, EXL2 scales, blocks != groups) ----
+
+def test_grid_options_match_reference():
+    g = load_golden("f9_grid_options")
+    w = t(g["w"])
+    for bits, sbw, mse in ((4, 4, False), (3, 4, True), (4, None, True), (4, 6, True)):
+        tag = f"b{bits}_s{sbw}_{'mse' if mse else 'nomse'}"
+        grid = oracle.find_params(w, bits, False, sbw, full=True)
+        if mse:
+            oracle.mse_refine(grid, w)
+        assert torch.equal(grid.scale, t(g[f"scale_{tag}"])), tag
+        assert torch.equal(grid.qzero, t(g[f"qzero_{tag}"])), tag
+        if sbw is not None:
+            assert torch.equal(grid.qscale, t(g[f"qscale_{tag}"])), tag
+            assert torch.equal(grid.sscale, t(g[f"sscale_{tag}"])), tag
+
+
+def test_mse_exact_sums_choose_the_references_candidates():
+    """The float64 error sums the HIP kernel uses pick the candidate the reference picks, except
+    where the reference's fp32 sums of two candidates are within rounding of each other."""
+    g = load_golden("f9_grid_options")
+    w = t(g["w"])
+    a = oracle.find_params(w, 4, False, None, full=True)
+    b = oracle.find_params(w, 4, False, None, full=True)
+    oracle.mse_refine(a, w)
+    oracle.mse_refine(b, w, exact=True)
+    same = (a.scale == b.scale).flatten()
+    assert same.float().mean() >= 0.9
+    p = oracle.shrink_candidates()
+    s0 = oracle.find_params(w, 4, False, None, full=True)
+    for r in torch.nonzero(~same).flatten().tolist():
+        x = w[r:r + 1, :, None]
+        sp = s0.scale[r:r + 1, :, None] * p
+        err = (oracle.dequantize(oracle.quantize(x, sp, s0.qzero[r:r + 1, :, None], s0.maxq), sp,
+                                 s0.qzero[r:r + 1, :, None]) - x).abs().pow(2.4).sum(dim=-2)[0]
+        ka = int(torch.argmin((s0.scale[r, 0] * p - a.scale[r, 0]).abs()))
+        kb = int(torch.argmin((s0.scale[r, 0] * p - b.scale[r, 0]).abs()))
+        assert err[kb] <= err[ka] * (1 + 1e-5), (r, ka, kb)
+
+
+def _check_meta_ex(res, g):
+    _check_meta(res, g)
+    meta = res["quant_meta"]
+    if "sscale" in g:
+        assert torch.equal(meta["qscale"], t(g["qscale"]))
+        assert torch.equal(meta["sscale"], t(g["sscale"]))
+    else:
+        assert meta["qscale"] is None and meta["sscale"] is None
+
+
+def _run_case(name):
+    g = load_golden(name)
+    hook = _hook_from(g) if "h_raw" in g else None
+    sbw = int(g["scale_bits"]) if "scale_bits" in g else None
+    res = oracle.gptq_quant(t(g["w"]), hook, t(g["group_sizes"]), t(g["group_bit_widths"]),
+                            use_kernel_semantics="kernelsem" in name, block_sizes=t(g["block_sizes"]),
+                            symmetric=bool(g["sym"]), scale_bit_width=sbw, mse=bool(g["mse"]))
+    return res, g
+
+
+@pytest.mark.parametrize("name", ["f8_kernelsem_mse_64x256_b4", "f8_kernelsem_exl2_64x256_mixed",
+                                  "f8_kernelsem_exl2_nomse_64x256", "f8_pysem_blocks128_g64_64x256",
+                                  "f8_pysem_blocks64_g128_64x256", "f8_pysem_mse_exl2_64x256",
+                                  "f8_rtn_mse_exl2_64x256"])
+def test_gptq_quant_options_match_reference(name):
+    res, g = _run_case(name)
+    _check_meta_ex(res, g)
+
+
+def test_mixed_exl2_groups_are_stored_sorted():
+    g = load_golden("f8_kernelsem_exl2_64x256_mixed")
+    assert g["group_sizes"].tolist() == [64, 128, 32, 32] and g["group_bit_widths"].tolist() == [3, 4, 4, 3]
+    assert g["meta_group_sizes"].tolist() == [128, 32, 64, 32]       # 4-bit groups first, larger first,
+    assert g["meta_group_bit_widths"].tolist() == [4, 4, 3, 3]       # earlier first among equals
