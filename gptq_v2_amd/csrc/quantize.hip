@@ -640,29 +640,60 @@ __device__ __forceinline__ float quantize2(float x, float s, float smaxq)
 }
 __device__ __forceinline__ float dequantize2(float q, float s) { return __fmul_rn(__fmul_rn(q, q), s); }
 
+// Up to GT groups handled by one launch (blockIdx.y = entry): their columns, bit widths, the columns
+// the shrink search looks at, and where their grids live (group index into the [G][R] arrays).
+constexpr int GT = 48;
+struct GroupTable {
+    int64_t col0[GT], m0[GT];
+    int ncols[GT], mn[GT], bits[GT], group[GT];
+};
+
+__global__ void find_params_table_kernel(const float *__restrict__ wt, int64_t r_total, GroupTable tab, int sym,
+                                         float *__restrict__ scale_g, float *__restrict__ zero_g)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r_total) return;
+    const int e = blockIdx.y;
+    const int64_t col0 = tab.col0[e];
+    float lo = 3.4e38f, hi = -3.4e38f, am = 0.0f;
+    for (int64_t c = col0; c < col0 + tab.ncols[e]; ++c) {
+        const float v = wt[c * r_total + r];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+        am = fmaxf(am, fabsf(v));
+    }
+    float sc, zr;
+    grid_from_minmax(lo, hi, am, (float)((1 << tab.bits[e]) - 1), sym, sc, zr);
+    scale_g[(int64_t)tab.group[e] * r_total + r] = sc;
+    zero_g[(int64_t)tab.group[e] * r_total + r] = zr;
+}
+
 // Quantizer.mse, PyTorch branch, rows (quant.py:151-155): every row tries the candidates
-// scale * shrink[k] and keeps the one with the smallest sum over columns [col0, col0 + ncols) of
+// scale * shrink[k] and keeps the one with the smallest sum over the search columns of
 // |dequantize(quantize(x)) - x| ^ norm (first minimum).  The quantisation is the reference's fp32
 // arithmetic; the error sums are accumulated in double, columns ascending.
 // Block (64 rows, 16 candidate slots); slot t takes candidates t, t + 16, ...
-__global__ __launch_bounds__(1024) void mse_rows_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0,
-                                                        int64_t ncols, float maxq, float *__restrict__ scale,
-                                                        const float *__restrict__ zero, const float *__restrict__ shrink,
-                                                        int n_shrink, double norm)
+__global__ __launch_bounds__(1024) void mse_rows_kernel(const float *__restrict__ wt, int64_t r_total, GroupTable tab,
+                                                        float *__restrict__ scale_g, const float *__restrict__ zero_g,
+                                                        const float *__restrict__ shrink, int n_shrink, double norm)
 {
     __shared__ double best_err[16][64];
     __shared__ int best_k[16][64];
     const int tx = threadIdx.x, ty = threadIdx.y;
+    const int e = blockIdx.y;
     const int64_t r = (int64_t)blockIdx.x * 64 + tx;
     const bool live = r < r_total;
     const int64_t rr = live ? r : r_total - 1;
-    const float s0 = scale[rr], z = zero[rr];
+    float *scale = scale_g + (int64_t)tab.group[e] * r_total;
+    const float s0 = scale[rr], z = zero_g[(int64_t)tab.group[e] * r_total + rr];
+    const float maxq = (float)((1 << tab.bits[e]) - 1);
+    const int64_t m0 = tab.m0[e], m1 = m0 + tab.mn[e];
     double be = 1.0e300 * 1.0e300;   // +inf
     int bk = 0x7fffffff;
     for (int k = ty; k < n_shrink; k += 16) {
         const float sp = __fmul_rn(s0, shrink[k]);
         double err = 0.0;
-        for (int64_t c = col0; c < col0 + ncols; ++c) {
+        for (int64_t c = m0; c < m1; ++c) {
             const float x = wt[c * r_total + rr];
             const float q = clampf(rintf(x / sp) + z, 0.0f, maxq);
             const float dq = __fmul_rn(__fsub_rn(q, z), sp);
@@ -678,10 +709,10 @@ __global__ __launch_bounds__(1024) void mse_rows_kernel(const float *__restrict_
     __syncthreads();
     if (ty == 0 && live) {
         for (int t = 1; t < 16; ++t) {
-            const double e = best_err[t][tx];
+            const double e2 = best_err[t][tx];
             const int k = best_k[t][tx];
-            if (e < be || (e == be && k < bk)) {
-                be = e;
+            if (e2 < be || (e2 == be && k < bk)) {
+                be = e2;
                 bk = k;
             }
         }
@@ -689,19 +720,22 @@ __global__ __launch_bounds__(1024) void mse_rows_kernel(const float *__restrict_
     }
 }
 
-// One workgroup per launch, one group of columns: the group's scales scale[R] go onto the quadratic
-// grid (quant.py:108-112), after an optional search for the best shrink of the grid's step
-// (quant.py:156-165: sum over rows of |dequantize2(quantize2(s)) - s| ^ norm, rows ascending,
-// accumulated in double, first minimum; thread k walks candidate k).
-__global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ scale, float *__restrict__ qscale,
-                                                         float *__restrict__ sscale_out, int64_t r_total, float smaxq,
-                                                         int search, const float *__restrict__ shrink, int n_shrink,
-                                                         double norm)
+// One workgroup per table entry: the group's scales go onto the quadratic grid (quant.py:108-112),
+// after an optional search for the best shrink of the grid's step (quant.py:156-165: sum over rows
+// of |dequantize2(quantize2(s)) - s| ^ norm in double, first minimum).  In the search thread t walks
+// candidate t % n_shrink over the rows t / n_shrink, + 256 / n_shrink, ...; the slices' sums are
+// added in slice order.
+__global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ scale_g, float *__restrict__ qscale_g,
+                                                         float *__restrict__ sscale_g, int64_t r_total, GroupTable tab,
+                                                         float smaxq, int search, const float *__restrict__ shrink,
+                                                         int n_shrink, double norm)
 {
     __shared__ float red[256];
     __shared__ double cand_err[256];
     __shared__ float ss_shared;
     const int tid = threadIdx.x;
+    const int g = tab.group[blockIdx.x];
+    float *scale = scale_g + (int64_t)g * r_total, *qscale = qscale_g + (int64_t)g * r_total;
     float m = -3.4e38f;
     for (int64_t r = tid; r < r_total; r += 256) m = fmaxf(m, scale[r]);
     red[tid] = m;
@@ -713,11 +747,12 @@ __global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ sca
     const float full = smaxq + 1.0f;
     float ss = red[0] / __fmul_rn(full, full) + 1e-12f;
     if (search) {
-        double err = 1.0e300 * 1.0e300;
-        if (tid < n_shrink) {
-            const float sp = __fmul_rn(ss, shrink[tid]);
-            err = 0.0;
-            for (int64_t r = 0; r < r_total; ++r) {
+        const int slices = 256 / n_shrink;   // n_shrink <= 256
+        const int k = tid % n_shrink, sl = tid / n_shrink;
+        double err = 0.0;
+        if (sl < slices) {
+            const float sp = __fmul_rn(ss, shrink[k]);
+            for (int64_t r = sl; r < r_total; r += slices) {
                 const float x = scale[r];
                 const float d = __fsub_rn(dequantize2(quantize2(x, sp, smaxq), sp), x);
                 err += pow((double)fabsf(d), norm);
@@ -727,12 +762,15 @@ __global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ sca
         __syncthreads();
         if (tid == 0) {
             int bk = 0;
-            double be = cand_err[0];
-            for (int k = 1; k < n_shrink && k < 256; ++k)
-                if (cand_err[k] < be) {
-                    be = cand_err[k];
-                    bk = k;
+            double be = 1.0e300 * 1.0e300;
+            for (int c = 0; c < n_shrink; ++c) {
+                double e = 0.0;
+                for (int q = 0; q < slices; ++q) e += cand_err[q * n_shrink + c];
+                if (e < be) {
+                    be = e;
+                    bk = c;
                 }
+            }
             ss_shared = __fmul_rn(ss, shrink[bk]);
         }
         __syncthreads();
@@ -743,7 +781,7 @@ __global__ __launch_bounds__(256) void exl2_scale_kernel(float *__restrict__ sca
         qscale[r] = q;
         scale[r] = dequantize2(q, ss);
     }
-    if (tid == 0) *sscale_out = ss;
+    if (tid == 0) sscale_g[g] = ss;
 }
 
 // qscale_g [G][R] fp32 -> qscale [R][G] uint8, sscale_g [G] fp32 -> sscale [G] (weight dtype)
@@ -857,27 +895,36 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
                          : launch_prep<GQ_BF16>(weight, perm, r, c, ws.wt, stream);
     if (rc) return rc;
 
-    // grid of group g from the working weights as they are now (quant.py:89-118), refined over
-    // columns [m0, m0 + mn) if the shrink search is on (quant.py:120-165)
-    auto grid_for_group = [&](int g, int64_t m0, int64_t mn) -> int {
-        const float maxq = (float)((1 << gb[g]) - 1);
-        float *sg = ws.scale_g + (int64_t)g * r, *zg = ws.zero_g + (int64_t)g * r, *qg = ws.qscale_g + (int64_t)g * r;
-        hipLaunchKernelGGL(find_params_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, ws.wt, r, gstart[g],
-                           (int64_t)gs[g], maxq, sym, sg, zg);
-        GQ_LAUNCH_CHECK();
-        if (exl2) {
-            hipLaunchKernelGGL(exl2_scale_kernel, dim3(1), dim3(256), 0, stream, sg, qg, ws.sscale_g + g, r, smaxq, 0,
-                               (const float *)nullptr, 0, 0.0);
-            GQ_LAUNCH_CHECK();
-        }
-        if (o.mse) {
-            hipLaunchKernelGGL(mse_rows_kernel, dim3((unsigned)gq_cdiv(r, 64)), dim3(64, 16), 0, stream, ws.wt, r, m0, mn, maxq,
-                               sg, zg, o.shrink, o.n_shrink, (double)o.norm);
+    // Grids of groups [g0, g1) from the working weights as they are now (quant.py:89-118).  With the
+    // shrink search on (quant.py:120-165) each group looks at its own columns (mn < 0) or all of them
+    // at columns [m0, m0 + mn).
+    auto grids_for = [&](int g0, int g1, int64_t m0, int64_t mn) -> int {
+        for (int base = g0; base < g1; base += GT) {
+            const int n = std::min(GT, g1 - base);
+            GroupTable tab{};
+            for (int e = 0; e < n; ++e) {
+                const int g = base + e;
+                tab.col0[e] = gstart[g]; tab.ncols[e] = gs[g]; tab.bits[e] = gb[g]; tab.group[e] = g;
+                tab.m0[e] = mn < 0 ? gstart[g] : m0;
+                tab.mn[e] = mn < 0 ? gs[g] : (int)mn;
+            }
+            hipLaunchKernelGGL(find_params_table_kernel, dim3((unsigned)gq_cdiv(r, 256), (unsigned)n), dim3(256), 0, stream,
+                               ws.wt, r, tab, sym, ws.scale_g, ws.zero_g);
             GQ_LAUNCH_CHECK();
             if (exl2) {
-                hipLaunchKernelGGL(exl2_scale_kernel, dim3(1), dim3(256), 0, stream, sg, qg, ws.sscale_g + g, r, smaxq, 1,
-                                   o.shrink, o.n_shrink, (double)o.norm);
+                hipLaunchKernelGGL(exl2_scale_kernel, dim3((unsigned)n), dim3(256), 0, stream, ws.scale_g, ws.qscale_g,
+                                   ws.sscale_g, r, tab, smaxq, 0, (const float *)nullptr, 1, 0.0);
                 GQ_LAUNCH_CHECK();
+            }
+            if (o.mse) {
+                hipLaunchKernelGGL(mse_rows_kernel, dim3((unsigned)gq_cdiv(r, 64), (unsigned)n), dim3(64, 16), 0, stream, ws.wt,
+                                   r, tab, ws.scale_g, ws.zero_g, o.shrink, o.n_shrink, (double)o.norm);
+                GQ_LAUNCH_CHECK();
+                if (exl2) {
+                    hipLaunchKernelGGL(exl2_scale_kernel, dim3((unsigned)n), dim3(256), 0, stream, ws.scale_g, ws.qscale_g,
+                                       ws.sscale_g, r, tab, smaxq, 1, o.shrink, o.n_shrink, (double)o.norm);
+                    GQ_LAUNCH_CHECK();
+                }
             }
         }
         return GQ_OK;
@@ -886,8 +933,8 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
 
     if (!u) {   // round to nearest (gptq_py.py:101-124)
         const unsigned rg = (unsigned)gq_cdiv(r, 256);
+        if ((rc = grids_for(0, n_groups, 0, -1))) return rc;
         for (int g = 0; g < n_groups; ++g) {
-            if ((rc = grid_for_group(g, gstart[g], gs[g]))) return rc;
             hipLaunchKernelGGL(rtn_kernel, dim3(rg), dim3(256), 0, stream, ws.wt, r, gstart[g], (int64_t)gs[g],
                                (float)((1 << gb[g]) - 1), ws.scale_g + (int64_t)g * r, ws.zero_g + (int64_t)g * r, ws.q_t, quant_t);
             GQ_LAUNCH_CHECK();
@@ -948,9 +995,8 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
                 hipLaunchKernelGGL(find_params_all_kernel, grid, dim3(256), 0, stream, ws.wt, r, (int)gs[0],
                                    (float)((1 << gb[0]) - 1), sym, ws.scale_g, ws.zero_g);
                 GQ_LAUNCH_CHECK();
-            } else {
-                for (int g = 0; g < n_groups; ++g)
-                    if ((rc = grid_for_group(g, gstart[g], gs[g]))) return rc;
+            } else if ((rc = grids_for(0, n_groups, 0, -1))) {
+                return rc;
             }
         }
 
@@ -970,9 +1016,8 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
             for (size_t k = i; k <= last; ++k) eager = std::max(eager, units[k].need_end);
             for (size_t k = i; k <= last; ++k) {
                 const Unit &un = units[k];
-                if (semantics == GQ_SEM_PYTHON && !in_kernel_grid)
-                    for (int g = un.g_first; g <= un.g_last; ++g)   // the search looks at the block (gptq_py.py:178-179)
-                        if ((rc = grid_for_group(g, un.col0, un.col1 - un.col0))) return rc;
+                if (semantics == GQ_SEM_PYTHON && !in_kernel_grid && un.g_first <= un.g_last)   // the search looks at the block (gptq_py.py:178-179)
+                    if ((rc = grids_for(un.g_first, un.g_last + 1, un.col0, un.col1 - un.col0))) return rc;
                 for (size_t l = un.first; l <= un.last; ++l) {
                     const Launch &la = launches[l];
                     QuantBlockArgs p{};

@@ -106,13 +106,17 @@ def quantize_llama(
         pack: bool = False,
         sets: Sequence[Sequence[str]] = LLAMA_SETS,
         on_set: Optional[Callable] = None,
+        symmetric: bool = False,
+        quant_mse: bool = False,
+        scale_bit_width: Optional[int] = None,
 ) -> Dict[str, Dict[str, dict]]:
     """Quantise every decoder block of ``model`` in place (llama.py:64-204).
 
     After the call each Linear holds the dense reconstructed weight (what the reference leaves in
     the model), or is replaced by a packed ``QuantLinear`` when ``pack`` is set.  ``on_set(block
     index, names, hessian_hook, weights)`` is called after each set's Hessian is inverted and
-    before its weights change (for inspection and tests)."""
+    before its weights change (for inspection and tests).  ``symmetric``, ``quant_mse`` and
+    ``scale_bit_width`` are the grid options the reference hard-codes to off (llama.py:146-163)."""
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
     use_cache, model.config.use_cache = model.config.use_cache, False
@@ -149,8 +153,10 @@ def quantize_llama(
             gb = torch.full([c // group_size], bits, dtype=torch.int32)
             if on_set is not None:
                 on_set(gi, list(names), hook, weights)
-            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
-                                  gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=device)
+            sbw = None if scale_bit_width is None else torch.tensor(int(scale_bit_width))
+            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
+                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
+                                  save_device=device)
             for name, mod, res in zip(names, mods, outs):
                 canonical = f"model.layers.{gi}.{name}"
                 meta = res["quant_meta"]
