@@ -1,0 +1,96 @@
+"""Parity cases at the shapes of the other configurations the hot path is quoted on: OPT-125M
+Linears (hidden 768, ffn 3072) against the CPU oracle, and the largest sizes of Llama-2-70B
+(down_proj: 28672 input features, 3-bit groups) through size-independent properties."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_hook(oracle, hook):
+    oh = oracle.OracleHessian()
+    oh.hessian, oh.hessian_inv = hook.hessian.cpu(), hook.hessian_inv.cpu()
+    if hook.perm is not None:
+        oh.perm, oh.perm_inv = hook.perm.cpu(), hook.perm_inv.cpu()
+    return oh
+
+
+@pytest.mark.parametrize("r,c", [(768, 768), (3072, 768), (768, 3072)])
+def test_opt125m_linear_shapes(amd, oracle, gpu, r, c):
+    """32 calibration sequences of 2048 tokens (as 4 batches of 8), 4-bit g128, act-order: the
+    Hessian against the oracle's fp32 addmm, then -- given the GPU's U and perm -- every integer
+    level, scale and zero of the native-loop semantics identical to the oracle's, and the
+    PyTorch-loop semantics within the tolerance of its fp32 summation order."""
+    gen = torch.Generator().manual_seed(r * 7 + c)
+    xs = [(torch.randn(8, 2048, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half() for _ in range(4)]
+    w = (torch.randn(r, c, generator=gen) * 0.02).half()
+    hook, oh = amd.HessianHook(), oracle.OracleHessian()
+    for x in xs:
+        hook.add_batch(x.to(gpu))
+        oh.add_batch(x)
+    assert hook.n_samples == oh.n_samples == 32
+    assert (hook.hessian.cpu() - oh.hessian).abs().max() <= 1e-5 * oh.hessian.abs().max()
+    hook.invert()
+    oh = _oracle_hook(oracle, hook)
+    gs = torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.full([c // 128], 4, dtype=torch.int32)
+    res = amd.gptq_quant(w.to(gpu), hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False)
+    want = oracle.gptq_quant(w, oh, gs, gb, use_kernel_semantics=True)
+    for k in ("qweight", "scale", "qzero", "perm_inv"):
+        assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
+    for k in ("gptq_error", "gptq_norm", "l2.0_error", "l2.0_norm"):
+        assert res["metrics"][k] == pytest.approx(want["metrics"][k], rel=1e-4), k
+    if r * c <= 768 * 768:   # the PyTorch loop of the oracle is slow; one shape is enough
+        res = amd.gptq_quant(w.to(gpu), hook, gs, gb, gptq_use_kernel=False, gptq_block_sizes=gs, quant_mse=False)
+        want = oracle.gptq_quant(w, oh, gs, gb, use_kernel_semantics=False, block_sizes=gs)
+        q, qr = res["quant_meta"]["qweight"].int(), want["quant_meta"]["qweight"].int()
+        assert (q - qr).abs().max() <= 1 and (q != qr).float().mean() <= 5e-3
+        assert torch.equal(res["quant_meta"]["scale"][:, 0], want["quant_meta"]["scale"][:, 0])
+
+
+def test_llama70b_down_proj_sizes(amd, gpu):
+    """C = 28672 input features (the largest Hessian of Llama-2-70B; int16 perm_inv still fits),
+    3-bit g128, a 256-row shard of the 8192 output features.  Properties that do not need a CPU
+    run: U is upper triangular with a positive diagonal and U H U^T = I for the damped, permuted H
+    the call leaves behind; perm is the descending order of the diagonal; every level is within
+    the 3-bit range and the dequantised weight is within half a step (plus the error feedback it
+    carries) of a weight that the feedback moved by a bounded amount."""
+    c, r, n = 28672, 256, 4096
+    gen = torch.Generator(device=gpu).manual_seed(11)
+    hook = amd.HessianHook()
+    for _ in range(2):
+        x = (torch.randn(1, n // 2, c, generator=gen, device=gpu) * (1 + 3 * torch.arange(c, device=gpu) / c)).half()
+        hook.add_batch(x)
+    del x
+    diag_before = hook.hessian.diagonal().clone()
+    u = hook.invert()
+    assert hook.tries == 1
+    assert torch.equal(hook.perm, torch.argsort(diag_before, descending=True, stable=True))
+    assert (u.diagonal() > 0).all() and torch.isfinite(u).all()
+    assert torch.count_nonzero(torch.tril(u[:4096, :4096], -1)) == 0 and torch.count_nonzero(u[-1, :-1]) == 0
+    # U H U^T = I, checked on row panels to bound memory
+    h = hook.hessian
+    worst = 0.0
+    for r0 in range(0, c, 4096):
+        t1 = torch.matmul(u[r0:r0 + 4096], h)                 # fp32
+        t2 = torch.matmul(t1, u[r0:r0 + 4096].t())            # (4096, 4096) diagonal block of U H U^T
+        worst = max(worst, float((t2 - torch.eye(4096, device=gpu)).abs().max()))
+        del t1, t2
+    assert worst < 5e-3, worst
+    w = (torch.randn(r, c, generator=gen, device=gpu) * 0.02).half()
+    gs = torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.full([c // 128], 3, dtype=torch.int32)
+    res = amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu)
+    meta = res["quant_meta"]
+    assert meta["perm_inv"].dtype == torch.int16 and int(meta["perm_inv"].max()) == c - 1
+    assert int(meta["qweight"].max()) <= 7
+    assert torch.equal(torch.sort(meta["perm_inv"].long()).values, torch.arange(c, device=gpu))
+    lin = amd.reconstruct_nn_linear(meta, dtype=torch.float16, device=gpu)
+    rel = float((lin.weight.float() - w.float()).norm() / w.float().norm())
+    assert 0.05 < rel < 0.35, rel     # 3-bit: far from exact, far from garbage
+    rtn = amd.gptq_quant(w, None, gs, gb, quant_mse=False, save_device=gpu)
+    # GPTQ trades weight error for output error: its Hessian-weighted error must beat round-to-nearest
+    def hessian_error(meta_):
+        d = (amd.reconstruct_nn_linear(meta_, torch.float16, gpu).weight.float() - w.float())[:, hook.perm]
+        return float(((d @ h) * d).sum())
+    assert hessian_error(meta) < 0.8 * hessian_error(rtn["quant_meta"])
