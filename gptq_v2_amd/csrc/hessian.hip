@@ -13,6 +13,7 @@
 //                   (L22, L22^-1) = rec(D);   (L^-1)21 = -L22^-1 (L21 L11^-1)
 // whose products run on the fp32 MFMA GEMM (sgemm.hip) and whose 128x128 leaves are factored and
 // inverted inside one workgroup in LDS.
+#include <type_traits>
 #include <vector>
 
 #include "sgemm.h"
@@ -141,6 +142,30 @@ __device__ __forceinline__ float readlane_f32(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// lane K of every 16-lane row, broadcast to that row (DPP row_newbcast)
+template <int K>
+__device__ __forceinline__ float row_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// 1 / sqrt(x): the hardware estimate and one Newton step
+__device__ __forceinline__ float rsqrt_nr(float x)
+{
+    const float r0 = __builtin_amdgcn_rsqf(x);
+    const float e = fmaf(-__fmul_rn(x, r0), r0, 1.0f);
+    return fmaf(__fmul_rn(0.5f, r0), e, r0);
+}
+
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
@@ -154,6 +179,16 @@ __device__ __forceinline__ void tri_index(int t, int &ti, int &tj)
     tj = t - r * (r + 1) / 2;
 }
 
+#ifdef GQ_LEAF_TRACE
+// Debug build only (tools/trace_leaf.py): cycles of thread 0 per phase, summed over the panels.
+__device__ unsigned long long *g_leaf_trace = nullptr;
+#define LF_T0() unsigned long long lf_t = __builtin_readcyclecounter(), lf_acc[8] = {}
+#define LF_ADD(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); lf_acc[i] += n_ - lf_t; lf_t = n_; } while (0)
+#else
+#define LF_T0()
+#define LF_ADD(i)
+#endif
+
 __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, float *__restrict__ linv, int64_t ld,
                                                    int64_t o, int *__restrict__ status)
 {
@@ -163,13 +198,23 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
     float *sc = x + NB * LLD;                         // [64][SLD]   product scratch
     float *tinv = sc + 64 * SLD;                      // [16][16]    inverse of the current diagonal block
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * (NB / 4); e += 256) {
-        const int r = e >> 5, c4 = (e & 31) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(w + (o + r) * ld + o + c4);
-        st4(a + r * LLD + c4, v);
-        st4(x + r * LLD + c4, f32x4{0.f, 0.f, 0.f, 0.f});
+    LF_T0();
+    {
+        f32x4 v[16];   // the 16 loads of a thread in flight together
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c4 = (e & 31) * 4;
+            v[q] = *reinterpret_cast<const f32x4 *>(w + (o + r) * ld + o + c4);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, c4 = (e & 31) * 4;
+            st4(a + r * LLD + c4, v[q]);
+            st4(x + r * LLD + c4, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
     }
     __syncthreads();
+    LF_ADD(0);
     bool bad = false;
 
     for (int p = 0; p < NB / PB; ++p) {
@@ -183,25 +228,36 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
                 const f32x4 v = lds4(a + (c0 + i) * LLD + c0 + k4);
                 d[k4] = v[0]; d[k4 + 1] = v[1]; d[k4 + 2] = v[2]; d[k4 + 3] = v[3];
             }
-#pragma unroll
-            for (int j = 0; j < PB; ++j) {
-                const float dj = readlane_f32(d[j], j);
+            // Right-looking factorisation, one pivot at a time.  Every 16-lane row of the wave holds the
+            // same 16 matrix rows, so the broadcasts are DPP row broadcasts folded into the fmas; the
+            // pivot's reciprocal square root (estimate + one Newton step) replaces the square root
+            // and the division, and is kept: the inverse below multiplies by it.
+            float rinv[PB];
+            static_for<0, PB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const float dj = row_bcast<j>(d[j]);
                 if (!(dj > 0.0f) || !(dj < 3.0e38f)) bad = true;
-                const float sj = sqrtf(dj);
-                const float lj = i == j ? sj : d[j] / sj;
+                const float rj = rsqrt_nr(dj);
+                const float lj = __fmul_rn(d[j], rj);   // lane j: dj / sqrt(dj) = sqrt(dj)
                 d[j] = lj;
-#pragma unroll
-                for (int k = j + 1; k < PB; ++k) d[k] = fmaf(-lj, readlane_f32(lj, k), d[k]);
-            }
-            // inverse: lane c holds column c, xi[i] = (L11^-1)[i][c]
+                rinv[j] = rj;
+                const float nlj = -lj;
+                static_for<j + 1, PB>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    d[k] = fmaf(nlj, row_bcast<k>(lj), d[k]);
+                });
+            });
+            // inverse: lane c holds column c, xi[r] = (L11^-1)[r][c]
             float xi[PB];
-#pragma unroll
-            for (int r = 0; r < PB; ++r) {
+            static_for<0, PB>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
                 float sacc = i == r ? 1.0f : 0.0f;
-#pragma unroll
-                for (int k = 0; k < r; ++k) sacc = fmaf(-readlane_f32(d[k], r), xi[k], sacc);
-                xi[r] = sacc / readlane_f32(d[r], r);
-            }
+                static_for<0, r>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    sacc = fmaf(-row_bcast<r>(d[k]), xi[k], sacc);
+                });
+                xi[r] = __fmul_rn(sacc, rinv[r]);
+            });
             if (tid < PB) {
 #pragma unroll
                 for (int k4 = 0; k4 < PB; k4 += 4) {
@@ -219,25 +275,51 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
             }
         }
         __syncthreads();
-        // (b) panel below the diagonal block: row t of  A21 * L11^-T
-        if (tid < NB && tid >= c1) {
-            float ar[PB], out[PB];
+        LF_ADD(1);
+        // (b) panel below the diagonal block: row t of  A21 * L11^-T, its 16 entries split over two
+        // threads (columns 0..11 and 12..15: 78 and 58 multiply-adds of the triangular product);
+        // the product replaces its own input, so everybody reads before anybody writes
+        {
+            const int row = tid & (NB - 1), hi = tid >> 7;
+            const bool act = row >= c1;
+            float ar[PB], out[12];
+            if (act) {
 #pragma unroll
-            for (int k4 = 0; k4 < PB; k4 += 4) {
-                const f32x4 v = lds4(a + tid * LLD + c0 + k4);
-                ar[k4] = v[0]; ar[k4 + 1] = v[1]; ar[k4 + 2] = v[2]; ar[k4 + 3] = v[3];
+                for (int k4 = 0; k4 < PB; k4 += 4) {
+                    const f32x4 v = lds4(a + row * LLD + c0 + k4);
+                    ar[k4] = v[0]; ar[k4 + 1] = v[1]; ar[k4 + 2] = v[2]; ar[k4 + 3] = v[3];
+                }
+                if (hi == 0) {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        float sacc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
+                        out[j] = sacc;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 12; j < PB; ++j) {
+                        float sacc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
+                        out[j - 12] = sacc;
+                    }
+                }
             }
+            __syncthreads();
+            if (act) {
+                if (hi == 0) {
 #pragma unroll
-            for (int j = 0; j < PB; ++j) {
-                float sacc = 0.0f;
-#pragma unroll
-                for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
-                out[j] = sacc;
+                    for (int k4 = 0; k4 < 12; k4 += 4)
+                        st4(a + row * LLD + c0 + k4, f32x4{out[k4], out[k4 + 1], out[k4 + 2], out[k4 + 3]});
+                } else {
+                    st4(a + row * LLD + c0 + 12, f32x4{out[0], out[1], out[2], out[3]});
+                }
             }
-#pragma unroll
-            for (int k4 = 0; k4 < PB; k4 += 4) st4(a + tid * LLD + c0 + k4, f32x4{out[k4], out[k4 + 1], out[k4 + 2], out[k4 + 3]});
         }
         __syncthreads();
+        LF_ADD(2);
         // (c) trailing lower triangle -= L21 L21^T, 4x4 tiles
         const int nt = (NB - c1) / 4;
         for (int t = tid; t < nt * (nt + 1) / 2; t += 256) {
@@ -266,6 +348,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
             for (int u = 0; u < 4; ++u) st4(a + (r0 + u) * LLD + q0, acc[u]);
         }
         __syncthreads();
+        LF_ADD(3);
     }
     if (__syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
 
@@ -300,6 +383,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
             for (int u = 0; u < 4; ++u) st4(dst + u * SLD, acc[u]);
         }
         __syncthreads();
+        LF_ADD(4);
         // pass 2: X21 = -X22 * T  (X22 lower triangular: k <= row)
         for (int t = tid; t < n_pairs * tiles_per_pair; t += 256) {
             const int pair = t / tiles_per_pair, tt = t % tiles_per_pair;
@@ -327,12 +411,29 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
             for (int u = 0; u < 4; ++u) st4(dst + u * LLD, acc[u]);
         }
         __syncthreads();
+        LF_ADD(5);
     }
     for (int e = tid; e < NB * (NB / 4); e += 256) {
         const int r = e >> 5, c4 = (e & 31) * 4;
         *reinterpret_cast<f32x4 *>(linv + (o + r) * ld + o + c4) = lds4(x + r * LLD + c4);
     }
+#ifdef GQ_LEAF_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LF_ADD(6);
+    if (g_leaf_trace && tid == 0 && o == 0)
+        for (int i = 0; i < 7; ++i) g_leaf_trace[i] = lf_acc[i];
+#endif
 }
+
+#ifdef GQ_LEAF_TRACE
+}  // namespace
+extern "C" int gq_debug_leaf_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_leaf_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+namespace {
+#endif
 
 // (L, L^-1) of w[o:o+n, o:o+n]; n is a multiple of 128.
 int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *status, hipStream_t stream)
