@@ -405,7 +405,9 @@ __device__ __forceinline__ void block_add(double v, double *dst, double *red)
     __syncthreads();
 }
 
-// sums[2] += (quant_t[j][r] - W[r][perm[j]])^2 over one 64x64 tile
+// sums[2] += (quant_t[j][r] - W[r][perm[j]])^2 over 64x64 tiles: blockIdx.x = row tile, the column
+// tiles are strided over blockIdx.y (a few hundred workgroups in all: each ends in one double
+// atomic on the same address, and thousands of those serialise)
 template <int DTYPE>
 __global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short *__restrict__ w,
                                                            const int32_t *__restrict__ perm, int64_t r_total,
@@ -414,45 +416,55 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short 
 {
     __shared__ float tile[64][65];
     __shared__ double red[256];
-    const int64_t r0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
-    load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
-    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int rr = threadIdx.x & 63;
     double acc = 0.0;
-    for (int pass = 0; pass < 16; ++pass) {
-        const int jj = (threadIdx.x >> 6) + 4 * pass;
-        if (j0 + jj < c_total && r0 + rr < r_total) {
-            const float d = quant_t[(j0 + jj) * r_total + r0 + rr] - tile[jj][rr];
-            acc += (double)d * (double)d;
+    for (int64_t j0 = (int64_t)blockIdx.y * 64; j0 < c_total; j0 += (int64_t)gridDim.y * 64) {
+        __syncthreads();
+        load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
+        __syncthreads();
+        for (int pass = 0; pass < 16; ++pass) {
+            const int jj = (threadIdx.x >> 6) + 4 * pass;
+            if (j0 + jj < c_total && r0 + rr < r_total) {
+                const float d = quant_t[(j0 + jj) * r_total + r0 + rr] - tile[jj][rr];
+                acc += (double)d * (double)d;
+            }
         }
     }
     block_add(acc, sums + 2, red);
 }
 
-// sums[0] += error^2 (flat), sums[1] += (W[r][j]/U[j][j])^2, sums[3] += W^2
+// sums[0] += error^2 (flat), sums[1] += (W[r][j]/U[j][j])^2, sums[3] += W^2.
+// Thread = one column j (its U[j][j] is loaded once) over the rows blockIdx.y, + gridDim.y, ...;
+// the error array has no structure the sum cares about and is walked flat.
 template <int DTYPE>
 __global__ __launch_bounds__(256) void metrics_flat_kernel(const unsigned short *__restrict__ w,
                                                            const float *__restrict__ u, const float *__restrict__ error_t,
                                                            int64_t r_total, int64_t c_total, double *__restrict__ sums)
 {
     __shared__ double red[256];
-    const int64_t total = r_total * c_total;
     double se = 0.0, sn = 0.0, sw = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        if (error_t) {
+    if (error_t) {
+        const int64_t total = r_total * c_total, n_threads = (int64_t)gridDim.x * gridDim.y * 256;
+        for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < total; i += n_threads) {
             const float e = error_t[i];
             se += (double)e * (double)e;
         }
-        const float wv = to_f32<DTYPE>(w[i]);
-        // the reference squares in the weight's own 16-bit type (gptq_py.py:237): round each square
-        float sq;
-        if constexpr (DTYPE == GQ_F16) sq = (float)(_Float16)(wv * wv);
-        else sq = (float)(__bf16)(wv * wv);
-        sw += (double)sq;
-        if (u) {
-            const int64_t j = i % c_total;
-            const float q = wv / u[j * c_total + j];
-            sn += (double)q * (double)q;
+    }
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < c_total) {
+        const float ujj = u ? u[j * c_total + j] : 1.0f;
+        for (int64_t r = blockIdx.y; r < r_total; r += gridDim.y) {
+            const float wv = to_f32<DTYPE>(w[r * c_total + j]);
+            // the reference squares in the weight's own 16-bit type (gptq_py.py:237): round each square
+            float sq;
+            if constexpr (DTYPE == GQ_F16) sq = (float)(_Float16)(wv * wv);
+            else sq = (float)(__bf16)(wv * wv);
+            sw += (double)sq;
+            if (u) {
+                const float q = wv / ujj;
+                sn += (double)q * (double)q;
+            }
         }
     }
     block_add(se, sums + 0, red);
@@ -1100,8 +1112,10 @@ extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *pe
     GQ_REQUIRE(r > 0 && c > 0, "gq_quant_metrics: bad shape");
     hipStream_t stream = (hipStream_t)stream_;
     GQ_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(double), stream));
-    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
-    const unsigned fg = (unsigned)std::min<int64_t>(gq_cdiv(r * c, 256), 4096);
+    // about 512 workgroups each
+    const int64_t rt = gq_cdiv(r, 64), cb = gq_cdiv(c, 256);
+    dim3 tgrid((unsigned)rt, (unsigned)std::max<int64_t>(1, std::min<int64_t>(gq_cdiv(c, 64), 512 / rt)));
+    dim3 fg((unsigned)cb, (unsigned)std::max<int64_t>(1, std::min<int64_t>(r, 512 / cb)));
     const unsigned short *w = (const unsigned short *)weight;
     if (dtype == GQ_F16) {
         hipLaunchKernelGGL(metrics_tile_kernel<GQ_F16>, tgrid, dim3(256), 0, stream, w, perm, r, c, quant_t, sums);

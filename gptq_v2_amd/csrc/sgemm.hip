@@ -1,12 +1,16 @@
 // fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32: every output element is one
 // k-ascending fma chain).  128x128 (or 64x64) tile per 256-thread workgroup, 2x2 waves,
 // 32-deep k-steps staged global -> registers -> LDS (two LDS stages, one barrier per step; the
-// next step's global loads are issued before this step's MFMAs and written to LDS after them).
+// global loads of step s + 2 are issued before the MFMAs of step s, and the registers of step s + 1
+// are written to LDS during them: a load has a step and a half to arrive, which matters when a
+// small product leaves one workgroup alone on its CU).
 //
 // LDS images, chosen by how the operand lies in memory so that global loads are 16-byte and
 // coalesced and fragment reads (one ds_read_b32 per lane per MFMA operand) are conflict-free:
 //   k-contiguous source (A_MK, B_NK): [128 rows][33 floats]   read at row*33 + k
 //   row-contiguous source (A_KM, B_KN): [32 k][128 floats]    read at k*128 + row
+#include <type_traits>
+
 #include "sgemm.h"
 
 namespace {
@@ -124,83 +128,119 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
         }
     }
     const int64_t inc_a = A_KM ? (int64_t)BKS * g.lda : BKS, inc_b = B_KN ? (int64_t)BKS * g.ldb : BKS;
-    Prefetch qa, qb;
-    auto gload = [&](int step) {
+    // 64-tiles keep the registers of two steps in flight (indexed by step parity); 128-tiles, which
+    // run two workgroups per CU and have no registers to spare, one
+    constexpr bool DEEP = BT == 64;
+    Prefetch qa[2], qb[2];
+    auto gload = [&](int step, Prefetch &da, Prefetch &db) {
         const int koff = step * BKS;
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
             f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
             if (oka[pass] && ka[pass] + koff < k_hi) va = *reinterpret_cast<const f32x4 *>(pa[pass]);
             if (okb[pass] && kb[pass] + koff < k_hi) vb = *reinterpret_cast<const f32x4 *>(pb[pass]);
-            qa.v[pass] = va;
-            qb.v[pass] = vb;
+            da.v[pass] = va;
+            db.v[pass] = vb;
             pa[pass] += inc_a;
             pb[pass] += inc_b;
         }
     };
     // piece `pass` of operand A or B into the LDS image of `stage`
-    auto lstore_a = [&](int stage, int pass) {
+    auto lstore_a = [&](int stage, int pass, const Prefetch &q) {
         float *ia = smem + stage * STAGE_FLOATS;
         if constexpr (A_KM) {
             constexpr int TPR = BT / 4, KPP = 256 / TPR;
-            *reinterpret_cast<f32x4 *>(ia + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = qa.v[pass];
+            *reinterpret_cast<f32x4 *>(ia + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
         } else {
             float *d = ia + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
-            d[0] = qa.v[pass][0]; d[1] = qa.v[pass][1]; d[2] = qa.v[pass][2]; d[3] = qa.v[pass][3];
+            d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
         }
     };
-    auto lstore_b = [&](int stage, int pass) {
+    auto lstore_b = [&](int stage, int pass, const Prefetch &q) {
         float *ib = smem + stage * STAGE_FLOATS + IMG_FLOATS;
         if constexpr (B_KN) {
             constexpr int TPR = BT / 4, KPP = 256 / TPR;
-            *reinterpret_cast<f32x4 *>(ib + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = qb.v[pass];
+            *reinterpret_cast<f32x4 *>(ib + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
         } else {
             float *d = ib + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
-            d[0] = qb.v[pass][0]; d[1] = qb.v[pass][1]; d[2] = qb.v[pass][2]; d[3] = qb.v[pass][3];
+            d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
         }
     };
 
     if (n_steps > 0) {
-        gload(0);
+        gload(0, qa[0], qb[0]);
+        if (DEEP && n_steps > 1) gload(1, qa[1], qb[1]);
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
-            lstore_a(0, pass);
-            lstore_b(0, pass);
+            lstore_a(0, pass, qa[0]);
+            lstore_b(0, pass, qb[0]);
         }
     }
     __syncthreads();
 #ifdef GQ_SG_TRACE
     const unsigned long long t_loop = __builtin_readcyclecounter();
 #endif
-    for (int step = 0; step < n_steps; ++step) {
-        const int cur = step & 1;
+    // one k-step; P = parity of `step`, the register set that held this step's data and is free again
+    auto k_step = [&](int step, auto par) {
+        constexpr int P = decltype(par)::value;
+        const int cur = P;
         const bool more = step + 1 < n_steps;
-        if (more) gload(step + 1);
+        if constexpr (DEEP) {
+            if (step + 2 < n_steps) gload(step + 2, qa[P], qb[P]);
+        } else {
+            if (more) gload(step + 1, qa[P ^ 1], qb[P ^ 1]);
+        }
         const float *ia = smem + cur * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+        if constexpr (DEEP) {
+            // one wave per SIMD: nobody hides the latency of the fragment reads, so all 32 of a step
+            // are issued before its first MFMA
+            float fa[BKS / 2], fb[BKS / 2];
+            const int ra = wr * 32 + li, rb = wc * 32 + li;
 #pragma unroll
-        for (int s = 0; s < BKS / 2; ++s) {
-            const int k = 2 * s + lh;
-            float fa[WB], fb[WB];
-#pragma unroll
-            for (int u = 0; u < WB; ++u) {
-                const int ra = (wr * WB + u) * 32 + li, rb = (wc * WB + u) * 32 + li;
-                fa[u] = sgn * (A_KM ? ia[k * BT + ra] : ia[ra * 33 + k]);
-                fb[u] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
+            for (int s = 0; s < BKS / 2; ++s) {
+                const int k = 2 * s + lh;
+                fa[s] = A_KM ? ia[k * BT + ra] : ia[ra * 33 + k];
+                fb[s] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
             }
 #pragma unroll
-            for (int a = 0; a < WB; ++a)
+            for (int s = 0; s < BKS / 2; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sgn * fa[s], fb[s], acc[0][0], 0, 0, 0);
+                if (more && s >= BKS / 2 - 2 * NP) {
+                    const int q = s - (BKS / 2 - 2 * NP);
+                    if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
+                    else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
+                }
+            }
+        } else {
 #pragma unroll
-                for (int b = 0; b < WB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            // the next step's pieces go to the other LDS stage one at a time in the second half of
-            // the step (their loads are half a step old by then), not in a burst before the barrier
-            if (more && s >= BKS / 2 - 2 * NP) {
-                const int q = s - (BKS / 2 - 2 * NP);
-                if (q & 1) lstore_b(cur ^ 1, q >> 1);
-                else lstore_a(cur ^ 1, q >> 1);
+            for (int s = 0; s < BKS / 2; ++s) {
+                const int k = 2 * s + lh;
+                float fa[WB], fb[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int ra = (wr * WB + u) * 32 + li, rb = (wc * WB + u) * 32 + li;
+                    fa[u] = sgn * (A_KM ? ia[k * BT + ra] : ia[ra * 33 + k]);
+                    fb[u] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
+                }
+#pragma unroll
+                for (int a = 0; a < WB; ++a)
+#pragma unroll
+                    for (int b = 0; b < WB; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                // the next step's pieces go to the other LDS stage one at a time in the second half of
+                // the step, not in a burst before the barrier
+                if (more && s >= BKS / 2 - 2 * NP) {
+                    const int q = s - (BKS / 2 - 2 * NP);
+                    if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
+                    else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
+                }
             }
         }
         __syncthreads();
+    };
+    for (int step = 0; step < n_steps; step += 2) {
+        k_step(step, std::integral_constant<int, 0>{});
+        if (step + 1 < n_steps) k_step(step + 1, std::integral_constant<int, 1>{});
     }
 #ifdef GQ_SG_TRACE
     const unsigned long long t_end = __builtin_readcyclecounter();
