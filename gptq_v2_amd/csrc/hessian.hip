@@ -54,24 +54,31 @@ __global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float rat
 }
 
 // Stable descending argsort by counting: rank(i) = #{j : d[j] > d[i] or (d[j] == d[i] and j < i)}.
-__global__ void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ perm,
-                                 int32_t *__restrict__ perm_inv)
+// A workgroup ranks 64 elements; its four waves each count one quarter of every 1024-value chunk.
+__global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ perm,
+                                                        int32_t *__restrict__ perm_inv)
 {
     __shared__ float chunk[1024];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int part[4][64];
+    const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     const float di = i < c ? diag[i] : 0.0f;
     int rank = 0;
     for (int base = 0; base < c; base += 1024) {
-        for (int t = threadIdx.x; t < 1024; t += blockDim.x) chunk[t] = base + t < c ? diag[base + t] : 0.0f;
+        for (int t = threadIdx.x; t < 1024; t += 256) chunk[t] = base + t < c ? diag[base + t] : 0.0f;
         __syncthreads();
-        const int lim = min(1024, c - base);
-        for (int t = 0; t < lim; ++t) {
+        const int lo = q * 256, lim = min(lo + 256, c - base);
+#pragma unroll 8
+        for (int t = lo; t < lim; ++t) {
             const float dj = chunk[t];
             rank += (dj > di) || (dj == di && base + t < i);
         }
         __syncthreads();
     }
-    if (i < c) {
+    part[q][tx] = rank;
+    __syncthreads();
+    if (q == 0 && i < c) {
+        rank = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
         perm[rank] = i;
         perm_inv[i] = rank;
     }
@@ -540,7 +547,7 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp);
     GQ_LAUNCH_CHECK();
     if (act_order) {
-        hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 256)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 64)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
         GQ_LAUNCH_CHECK();
         hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, ws.t);
         GQ_LAUNCH_CHECK();
