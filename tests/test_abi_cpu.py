@@ -1,0 +1,68 @@
+"""The C ABI without a GPU: libgptq_amd.so loads, exports every function include/gptq_amd.h
+declares (and the ctypes table binds exactly those), and rejects bad arguments before touching the
+device.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "gptq_amd.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments out
+    text = re.sub(r"typedef struct .*?\} \w+;", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gq_\w+)\s*\(", text)))
+
+
+def test_header_declares_what_we_think():
+    names = _declared()
+    for must in ("gq_xtx_accumulate", "gq_hessian_invert", "gq_quantize_range", "gq_quantize_layer",
+                 "gq_quantize_layer_ex", "gq_quantize_rtn", "gq_dequantize", "gq_pack_rows", "gq_w4a16_gemm"):
+        assert must in names
+    assert len(names) == 17
+
+
+def test_library_exports_every_declared_symbol():
+    from gptq_v2_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} is declared in gptq_amd.h but not exported"
+
+
+def test_ctypes_table_matches_the_header():
+    from gptq_v2_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    _lib.load()   # binds restype / argtypes of every entry; AttributeError if one is missing
+
+
+def test_grid_options_struct_layout():
+    """struct gq_grid_options: int, int, int, pointer, int, float -- 8-byte aligned pointer."""
+    from gptq_v2_amd import _lib
+    o = _lib.GridOptions
+    assert (o.sym.offset, o.scale_bits.offset, o.mse.offset) == (0, 4, 8)
+    assert o.shrink.offset == 16 and o.n_shrink.offset == 24 and o.norm.offset == 28
+    assert ctypes.sizeof(o) == 32
+
+
+def test_bad_arguments_are_rejected_before_the_device_is_touched():
+    from gptq_v2_amd import _lib
+    lib = _lib.load()
+    assert lib.gq_version() >= 1
+    assert lib.gq_hessian_invert_workspace(0) == 0 and lib.gq_hessian_invert_workspace(4096) > 3 * 4096 * 4096 * 4
+    assert lib.gq_quantize_layer_workspace(0, 5) == 0 and lib.gq_quantize_layer_workspace(64, 128) > 0
+    assert lib.gq_xtx_accumulate(None, None, 0, 16, 16, 0, 1, None) == -1
+    assert b"NULL" in lib.gq_last_error()
+    one = ctypes.c_void_p(256)   # never dereferenced: the argument checks come first
+    assert lib.gq_xtx_accumulate(one, one, 7, 16, 16, 0, 1, None) == -1          # dtype code
+    assert lib.gq_xtx_accumulate(one, one, 0, 16, 16, 1, 0, None) == -1          # save_lower_only without compute_lower_only
+    assert lib.gq_w4a16_gemm(one, one, one, one, one, 8, 64, 100, 128, None) == -1   # in_features not a multiple of 64
+    assert lib.gq_pack_rows(one, 4, 64, 5, 0, one, None) == -1                    # 5-bit values
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(_lib.GqError):
+        _lib.check(-2, "x")
