@@ -8,10 +8,12 @@ the outputs of the sets already quantised before it; then run the quantised bloc
 next block's inputs.  The result dictionary has the reference's shape
 ``{'data': {name: quant_meta}, 'metrics': {name: metrics}}`` (llama.py:82-85, 167-173).
 
-Differences in construction, not in result: inputs are captured with forward pre-hooks (the block
-is re-run up to the hooked Linear, which is cheap next to the quantisation) instead of the
-reference's fake-tensor dependency discovery, the Linears of a set are quantised together
-(``gptq_quant_set``), and everything stays on the GPU.
+Differences in construction, not in result: inputs are captured with forward pre-hooks instead of
+the reference's fake-tensor dependency discovery, the Linears of a set are quantised together
+(``gptq_quant_set``), and everything stays on the GPU.  A block with the Llama layout is walked in
+stages -- attention once, then ``x + o_proj(.)``, the second norm, ``act(gate) * up`` and the
+final residual from cached activations -- so every sub-module runs once per block; any other
+block is re-run up to the hooked Linear once per set.
 """
 from __future__ import annotations
 
@@ -63,6 +65,19 @@ def _submodule(block: nn.Module, dotted: str) -> nn.Module:
     return mod
 
 
+def _is_llama_layout(block: nn.Module, sets) -> bool:
+    """The decoder layout the staged walk assumes (LlamaDecoderLayer): x + attn(norm1(x)), then
+    h + down(act(gate(norm2(h))) * up(norm2(h))), Linears without bias, default sets."""
+    if [list(s_) for s_ in sets] != LLAMA_SETS:
+        return False
+    try:
+        mods = [_submodule(block, nm) for names in LLAMA_SETS for nm in names]
+        ok = callable(block.mlp.act_fn) and isinstance(block.post_attention_layernorm, nn.Module)
+    except AttributeError:
+        return False
+    return ok and type(block).__name__ == "LlamaDecoderLayer" and all(getattr(m, "bias", None) is None for m in mods)
+
+
 @torch.no_grad()
 def get_initial_inputs(model: nn.Module, encodings: torch.Tensor, device: torch.device,
                        batch_size: int = 1) -> Tuple[torch.Tensor, dict]:
@@ -109,6 +124,7 @@ def quantize_llama(
         symmetric: bool = False,
         quant_mse: bool = False,
         scale_bit_width: Optional[int] = None,
+        staged: Optional[bool] = None,
 ) -> Dict[str, Dict[str, dict]]:
     """Quantise every decoder block of ``model`` in place (llama.py:64-204).
 
@@ -116,63 +132,114 @@ def quantize_llama(
     the model), or is replaced by a packed ``QuantLinear`` when ``pack`` is set.  ``on_set(block
     index, names, hessian_hook, weights)`` is called after each set's Hessian is inverted and
     before its weights change (for inspection and tests).  ``symmetric``, ``quant_mse`` and
-    ``scale_bit_width`` are the grid options the reference hard-codes to off (llama.py:146-163)."""
+    ``scale_bit_width`` are the grid options the reference hard-codes to off (llama.py:146-163).
+    ``staged``: walk Llama-layout blocks in stages from cached activations (None: when the block
+    has that layout; False: always re-run the block up to each hooked Linear)."""
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
     use_cache, model.config.use_cache = model.config.use_cache, False
     dtype = inps.dtype
     results: Dict[str, Dict[str, dict]] = {"data": {}, "metrics": {}, "seconds_per_block": []}
 
+    sbw = None if scale_bit_width is None else torch.tensor(int(scale_bit_width))
+    n = len(inps)
+    batches = [(bi, min(n, bi + batch_size)) for bi in range(0, n, batch_size)]
+
+    def quantise_set(gi, block, names, hook):
+        """invert + quantise + put the results into the block; the Hessian is complete"""
+        mods = [_submodule(block, nm) for nm in names]
+        hook.invert(damp_ratio=damp_ratio, act_order=act_order)
+        weights = [m.weight.data for m in mods]
+        c = weights[0].shape[1]
+        if c % group_size:
+            raise ValueError(f"in_features {c} is not a multiple of the group size {group_size}")
+        gs = torch.full([c // group_size], group_size, dtype=torch.int32)
+        gb = torch.full([c // group_size], bits, dtype=torch.int32)
+        if on_set is not None:
+            on_set(gi, list(names), hook, weights)
+        outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
+                              gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
+                              save_device=device)
+        for name, mod, res in zip(names, mods, outs):
+            canonical = f"model.layers.{gi}.{name}"
+            meta = res["quant_meta"]
+            results["metrics"][canonical] = res["metrics"]
+            results["data"][canonical] = _to_device(meta, torch.device("cpu"))
+            if pack:
+                layer = QuantLinear.from_quant_meta(meta, device)
+                parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
+                setattr(parent, name.rsplit(".", 1)[-1], layer)
+            else:
+                mod.weight.data = reconstruct_weight(meta, dtype, device)
+
+    def run_until(block, name, hook, keep=None):
+        """forward of every batch up to the input of sub-module `name`: into the Hessian, and into
+        `keep` (a preallocated tensor) if given"""
+        pos = [0]
+
+        def feed(_mod, args):
+            x = args[0]
+            hook.add_batch(x)
+            if keep is not None:
+                keep[pos[0]:pos[0] + len(x)] = x
+            pos[0] += len(x)
+            raise _Stop()
+
+        handle = _submodule(block, name).register_forward_pre_hook(feed)
+        try:
+            for b, e in batches:
+                try:
+                    block(inps[b:e], **inp_kwargs)
+                except _Stop:
+                    pass
+        finally:
+            handle.remove()
+
     for gi, block in enumerate(model.model.layers):
         t0 = time.time()
         block.to(device)
-        for names in sets:
-            mods = [_submodule(block, n) for n in names]
-            hook = HessianHook()
-
-            def feed(_mod, args, _hook=hook):
-                _hook.add_batch(args[0])
-                raise _Stop()
-
-            handle = mods[0].register_forward_pre_hook(feed)
-            try:
-                for bi in range(0, len(inps), batch_size):
-                    try:
-                        block(inps[bi:bi + batch_size], **inp_kwargs)
-                    except _Stop:
-                        pass
-            finally:
-                handle.remove()
-            hook.invert(damp_ratio=damp_ratio, act_order=act_order)
-
-            weights = [m.weight.data for m in mods]
-            c = weights[0].shape[1]
-            if c % group_size:
-                raise ValueError(f"in_features {c} is not a multiple of the group size {group_size}")
-            gs = torch.full([c // group_size], group_size, dtype=torch.int32)
-            gb = torch.full([c // group_size], bits, dtype=torch.int32)
-            if on_set is not None:
-                on_set(gi, list(names), hook, weights)
-            sbw = None if scale_bit_width is None else torch.tensor(int(scale_bit_width))
-            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
-                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
-                                  save_device=device)
-            for name, mod, res in zip(names, mods, outs):
-                canonical = f"model.layers.{gi}.{name}"
-                meta = res["quant_meta"]
-                results["metrics"][canonical] = res["metrics"]
-                results["data"][canonical] = _to_device(meta, torch.device("cpu"))
-                if pack:
-                    layer = QuantLinear.from_quant_meta(meta, device)
-                    parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
-                    setattr(parent, name.rsplit(".", 1)[-1], layer)
-                else:
-                    mod.weight.data = reconstruct_weight(meta, dtype, device)
-            del hook, outs
-
         nxt = torch.empty_like(inps)
-        for bi in range(0, len(inps), batch_size):
-            nxt[bi:bi + batch_size] = _first(block(inps[bi:bi + batch_size], **inp_kwargs))
+        if _is_llama_layout(block, sets) if staged is None else staged:
+            # stage 1: q, k, v see the first norm's output
+            hook = HessianHook()
+            run_until(block, sets[0][0], hook)
+            quantise_set(gi, block, sets[0], hook)
+            # stage 2: attention once; its output is o_proj's input
+            hook = HessianHook()
+            attn = torch.empty(n, inps.shape[1], _submodule(block, sets[1][0]).in_features, dtype=dtype, device=device)
+            run_until(block, sets[1][0], hook, keep=attn)
+            quantise_set(gi, block, sets[1], hook)
+            # stage 3: h = x + o_proj(attn), z = norm2(h) feeds gate and up
+            hook = HessianHook()
+            o_proj = _submodule(block, sets[1][0])
+            h, z = torch.empty_like(inps), torch.empty_like(inps)
+            for b, e in batches:
+                h[b:e] = inps[b:e] + o_proj(attn[b:e])
+                z[b:e] = block.post_attention_layernorm(h[b:e])
+                hook.add_batch(z[b:e])
+            del attn
+            quantise_set(gi, block, sets[2], hook)
+            # stage 4: a = act(gate(z)) * up(z) feeds down
+            hook = HessianHook()
+            gate, up = _submodule(block, sets[2][0]), _submodule(block, sets[2][1])
+            act = torch.empty(n, inps.shape[1], gate.out_features, dtype=dtype, device=device)
+            for b, e in batches:
+                act[b:e] = block.mlp.act_fn(gate(z[b:e])) * up(z[b:e])
+                hook.add_batch(act[b:e])
+            del z
+            quantise_set(gi, block, sets[3], hook)
+            down = _submodule(block, sets[3][0])
+            for b, e in batches:
+                nxt[b:e] = h[b:e] + down(act[b:e])
+            del h, act, hook
+        else:
+            for names in sets:
+                hook = HessianHook()
+                run_until(block, names[0], hook)
+                quantise_set(gi, block, names, hook)
+                del hook
+            for b, e in batches:
+                nxt[b:e] = _first(block(inps[b:e], **inp_kwargs))
         inps = nxt
         results["seconds_per_block"].append(time.time() - t0)
 

@@ -123,3 +123,23 @@ def test_results_round_trip_through_the_reference_file_format(amd, gpu, tmp_path
     p_dense = float(driver.evaluate_llama(dense, enc, gpu, batch_size=4))
     p_packed = float(driver.evaluate_llama(packed, enc, gpu, batch_size=4))
     assert abs(p_dense - p_packed) / p_dense < 0.02
+
+
+@pytest.mark.parametrize("pack", [False, True])
+def test_staged_walk_equals_rerun_walk(amd, gpu, pack):
+    """Llama-layout blocks are walked in stages from cached activations (every sub-module runs once
+    per block); the generic walk re-runs the block up to each hooked Linear.  Same inputs to every
+    Hessian, so every stored tensor and the final model output are identical."""
+    from gptq_v2_amd import driver
+    model = _tiny_llama(seed=3)
+    enc = torch.randint(0, 512, (12, 64), generator=torch.Generator().manual_seed(4))
+    a, b = copy.deepcopy(model), copy.deepcopy(model)
+    assert driver._is_llama_layout(a.model.layers[0], driver.LLAMA_SETS)
+    ra = driver.quantize_llama(a, enc, gpu, batch_size=5, pack=pack, staged=None)     # ragged last batch
+    rb = driver.quantize_llama(b, enc, gpu, batch_size=5, pack=pack, staged=False)
+    for name in ra["data"]:
+        for k in ("qweight", "scale", "qzero", "perm_inv"):
+            assert torch.equal(ra["data"][name][k], rb["data"][name][k]), (name, k)
+    pa = float(driver.evaluate_llama(a, enc, gpu, batch_size=4))
+    pb = float(driver.evaluate_llama(b, enc, gpu, batch_size=4))
+    assert pa == pb
