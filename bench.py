@@ -90,6 +90,9 @@ def make_inputs(dev, n_local, seed):
 
 
 VERBOSE = bool(os.environ.get("GQ_BENCH_VERBOSE"))
+if VERBOSE:   # a stuck rank shows where: Python stacks of all threads every two minutes
+    import faulthandler
+    faulthandler.dump_traceback_later(120, repeat=True, file=sys.stderr)
 
 
 def note(rank, msg):
@@ -124,6 +127,9 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
             results = amd.gptq_quant_set([w[rb:re] for w, (rb, re) in zip(weights, shards)], hook, gs, gb,
                                          scale_bit_width=None, gptq_use_kernel=True, gptq_block_sizes=gs,
                                          quant_symmetric=False, quant_mse=False, save_device=dev)
+        if VERBOSE:
+            torch.cuda.synchronize()
+            note(rank, "quantised")
         for w, res in zip(weights, results):
             r = w.shape[0]
             meta = res["quant_meta"]
@@ -132,6 +138,7 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
                 with phases["allgather"]:
                     full = gd.allgather_rows({k: meta[k] for k in ("qweight", "scale", "qzero")}, r)
                     meta = dict(meta, **full)
+            note(rank, "reconstruct + pack")
             with phases["reconstruct"]:
                 lin = amd.reconstruct_nn_linear(meta, dtype=torch.float16, device=dev)
                 del lin
@@ -141,6 +148,7 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
         del results
         # replay (llama.py:176-177): the Linears of a set share the input and its act-order, so each
         # batch is gathered into permuted column order once and fed to every layer of the set
+        note(rank, "replay")
         for bi in range(0, x.shape[0], batch):
             with phases["permute"]:
                 xp = layers[0].permute_input(x[bi:bi + batch])

@@ -46,8 +46,14 @@ def allreduce_hessian(hessian: torch.Tensor, n_samples: int) -> int:
     rank, ws = world()
     if ws == 1:
         return n_samples
-    dist.all_reduce(hessian, op=dist.ReduceOp.SUM)
-    n = torch.tensor([n_samples], dtype=torch.int64, device=hessian.device)
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(hessian, op=dist.ReduceOp.SUM)
+        n = torch.tensor([n_samples], dtype=torch.int64, device=hessian.device)
+    else:   # gloo (CPU tests, single-GPU rehearsals): through host memory, see allgather_rows
+        host = hessian.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        hessian.copy_(host)
+        n = torch.tensor([n_samples], dtype=torch.int64)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return int(n.item())
 
@@ -68,7 +74,12 @@ def allgather_rows(local: Dict[str, torch.Tensor], n_rows: int, multiple: int = 
         gathered = torch.empty((ws, most) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
         if dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(gathered.view(ws * most, *part.shape[1:]), mine)
-        else:   # gloo (CPU tests, single-GPU rehearsals): the list form is the one it implements everywhere
-            dist.all_gather([gathered[r] for r in range(ws)], mine)
+        else:
+            # gloo (CPU tests, single-GPU rehearsals): the list form is the one it implements everywhere,
+            # and device tensors go through host memory here (its own device path hung on 22 MB pieces)
+            host = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(ws)]
+            dist.all_gather(host, mine.cpu())
+            for r in range(ws):
+                gathered[r].copy_(host[r])
         out[name] = torch.cat([gathered[r, : e - b] for r, (b, e) in enumerate(bounds)], dim=0)
     return out
