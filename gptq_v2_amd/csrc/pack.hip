@@ -115,7 +115,11 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const unsigned short 
 // Wide variant (c a multiple of 8, c < 65536, 16-byte aligned rows): a workgroup keeps the
 // permutation in LDS as 16-bit indices and walks PR consecutive rows; rows are staged with 16-byte
 // loads, every thread gathers 8 neighbouring outputs from LDS and writes them with one 16-byte store.
+// NP = 16-byte pieces of a row per thread (c <= NP * 2048): the next row is loaded into registers
+// before the current one is gathered and goes to LDS after it, so the load latency hides behind the
+// gather instead of stalling every row.
 constexpr int PR = 16;
+template <int NP>
 __global__ __launch_bounds__(256) void permute_cols_wide_kernel(const unsigned short *__restrict__ x, const int32_t *__restrict__ perm,
                                                                 int64_t m, int64_t c, unsigned short *__restrict__ out)
 {
@@ -123,27 +127,44 @@ __global__ __launch_bounds__(256) void permute_cols_wide_kernel(const unsigned s
     unsigned short *pidx = (unsigned short *)smem;          // c entries
     unsigned short *row = pidx + c;                          // 2 x c entries (two rows in flight)
     const int tid = threadIdx.x;
+    const int n16 = (int)(c / 8);
     for (int64_t j = tid; j < c; j += 256) pidx[j] = (unsigned short)perm[j];
     const int64_t m_lo = (int64_t)blockIdx.x * PR, m_hi = m_lo + PR < m ? m_lo + PR : m;
-    auto stage = [&](int64_t mm, unsigned short *dst) {
+    u32x4 pre[NP];
+    auto fetch = [&](int64_t mm) {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(x + mm * c);
-        for (int64_t j = tid; j < c / 8; j += 256) reinterpret_cast<u32x4 *>(dst)[j] = src[j];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + 256 * i < n16) pre[i] = src[tid + 256 * i];
     };
-    if (m_lo < m_hi) stage(m_lo, row);
+    auto put = [&](unsigned short *dst) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + 256 * i < n16) reinterpret_cast<u32x4 *>(dst)[tid + 256 * i] = pre[i];
+    };
+    if (m_lo < m_hi) {
+        fetch(m_lo);
+        put(row);
+    }
     __syncthreads();
     for (int64_t mm = m_lo; mm < m_hi; ++mm) {
         unsigned short *cur = row + ((mm - m_lo) & 1) * c, *nxt = row + ((mm - m_lo + 1) & 1) * c;
-        if (mm + 1 < m_hi) stage(mm + 1, nxt);
-        for (int64_t j = tid; j < c / 8; j += 256) {
-            const u32x4 pi = reinterpret_cast<const u32x4 *>(pidx)[j];
-            u32x4 o;
+        if (mm + 1 < m_hi) fetch(mm + 1);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned lo = cur[pi[w] & 0xffffu], hi = cur[pi[w] >> 16];
-                o[w] = lo | (hi << 16);
+        for (int i = 0; i < NP; ++i) {
+            const int j = tid + 256 * i;
+            if (j < n16) {
+                const u32x4 pi = reinterpret_cast<const u32x4 *>(pidx)[j];
+                u32x4 o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned lo = cur[pi[w] & 0xffffu], hi = cur[pi[w] >> 16];
+                    o[w] = lo | (hi << 16);
+                }
+                reinterpret_cast<u32x4 *>(out + mm * c)[j] = o;
             }
-            reinterpret_cast<u32x4 *>(out + mm * c)[j] = o;
         }
+        if (mm + 1 < m_hi) put(nxt);
         __syncthreads();
     }
 }
@@ -211,10 +232,14 @@ extern "C" int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t
     GQ_REQUIRE(m >= 0 && c > 0 && c <= 80 * 1024, "gq_permute_columns: bad shape");
     GQ_REQUIRE(x_in != x_out, "gq_permute_columns: in-place is not supported");
     if (m == 0) return GQ_OK;
-    if (c % 8 == 0 && c < 65536 && c * 6 <= 150 * 1024 && (((uintptr_t)x_in | (uintptr_t)x_out) & 15) == 0) {
+    if (c % 8 == 0 && c <= 8 * 2048 && (((uintptr_t)x_in | (uintptr_t)x_out) & 15) == 0) {
         const size_t lds_w = (size_t)(c * 6);
-        GQ_HIP(hipFuncSetAttribute((const void *)permute_cols_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
-        hipLaunchKernelGGL(permute_cols_wide_kernel, dim3((unsigned)gq_cdiv(m, PR)), dim3(256), lds_w, (hipStream_t)stream,
+        const int np = (int)gq_cdiv(c / 8, 256);
+        void (*kern)(const unsigned short *, const int32_t *, int64_t, int64_t, unsigned short *) =
+            np <= 2 ? permute_cols_wide_kernel<2> : np <= 4 ? permute_cols_wide_kernel<4>
+            : np <= 6 ? permute_cols_wide_kernel<6> : permute_cols_wide_kernel<8>;
+        GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        hipLaunchKernelGGL(kern, dim3((unsigned)gq_cdiv(m, PR)), dim3(256), lds_w, (hipStream_t)stream,
                            (const unsigned short *)x_in, perm, m, c, (unsigned short *)x_out);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
