@@ -136,23 +136,33 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
     const float *__restrict__ wbase = wt + (int64_t)a * r_total;
     const float *__restrict__ ubase = u + (int64_t)a * ldu + a;
     {
+        // (U first: behind the weight loads hipcc forms these addresses with an instruction that names a
+        // register still being loaded, and waits for it)
+        // The loads of the U square are unconditional, from addresses clamped into the square, and
+        // masked afterwards: a load under a divergent branch makes hipcc drain every older load first
+        // (vmcnt(0) in front of each), which turned these 16 loads into 16 round trips.
+        const int trow = tid >> 5, c4 = (tid & 31) * 4;
+        const unsigned c4c = c4 < bs ? (unsigned)c4 : 0u;
+        f32x4 ureg[QB / 8];
+#pragma unroll
+        for (int i = 0; i < QB / 8; ++i) {
+            const int row = trow + 8 * i;
+            const unsigned rowc = row < bs ? (unsigned)row : 0u;
+            ureg[i] = *reinterpret_cast<const f32x4 *>(ubase + (rowc * lu + c4c));
+        }
+        const unsigned tc = tid < bs ? (unsigned)tid : 0u;
+        float dg = ubase[tc * lu + tc];
         float wreg[QB / 4];
 #pragma unroll
         for (int i = 0; i < QB / 4; ++i) {
             const int c = wv + 4 * i;
             wreg[i] = c < bs ? wbase[(unsigned)c * rt + (unsigned)rr] : 0.0f;
         }
-        const int trow = tid >> 5, c4 = (tid & 31) * 4;
-        const unsigned uoff = (unsigned)trow * lu + (unsigned)c4;
-        f32x4 ureg[QB / 8];
+        __builtin_amdgcn_sched_barrier(0);   // every load is issued before the first result is touched
 #pragma unroll
-        for (int i = 0; i < QB / 8; ++i) {
-            const int row = trow + 8 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < bs && c4 < bs) v = *reinterpret_cast<const f32x4 *>(ubase + (uoff + (unsigned)(8 * i) * lu));
-            ureg[i] = v;
-        }
-        const float dg = tid < bs ? ubase[(unsigned)tid * lu + (unsigned)tid] : 1.0f;
+        for (int i = 0; i < QB / 8; ++i)
+            if (!(trow + 8 * i < bs && c4 < bs)) ureg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid >= bs) dg = 1.0f;
         QB_TR(34);
 #pragma unroll
         for (int i = 0; i < QB / 4; ++i) wl[wv + 4 * i][lane] = wreg[i];
