@@ -128,119 +128,152 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
         }
     }
     const int64_t inc_a = A_KM ? (int64_t)BKS * g.lda : BKS, inc_b = B_KN ? (int64_t)BKS * g.ldb : BKS;
-    // 64-tiles keep the registers of two steps in flight (indexed by step parity); 128-tiles, which
-    // run two workgroups per CU and have no registers to spare, one
-    constexpr bool DEEP = BT == 64;
-    Prefetch qa[2], qb[2];
-    auto gload = [&](int step, Prefetch &da, Prefetch &db) {
-        const int koff = step * BKS;
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (oka[pass] && ka[pass] + koff < k_hi) va = *reinterpret_cast<const f32x4 *>(pa[pass]);
-            if (okb[pass] && kb[pass] + koff < k_hi) vb = *reinterpret_cast<const f32x4 *>(pb[pass]);
-            da.v[pass] = va;
-            db.v[pass] = vb;
-            pa[pass] += inc_a;
-            pb[pass] += inc_b;
-        }
-    };
-    // piece `pass` of operand A or B into the LDS image of `stage`
-    auto lstore_a = [&](int stage, int pass, const Prefetch &q) {
-        float *ia = smem + stage * STAGE_FLOATS;
-        if constexpr (A_KM) {
-            constexpr int TPR = BT / 4, KPP = 256 / TPR;
-            *reinterpret_cast<f32x4 *>(ia + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
-        } else {
-            float *d = ia + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
-            d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
-        }
-    };
-    auto lstore_b = [&](int stage, int pass, const Prefetch &q) {
-        float *ib = smem + stage * STAGE_FLOATS + IMG_FLOATS;
-        if constexpr (B_KN) {
-            constexpr int TPR = BT / 4, KPP = 256 / TPR;
-            *reinterpret_cast<f32x4 *>(ib + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
-        } else {
-            float *d = ib + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
-            d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
-        }
-    };
-
-    if (n_steps > 0) {
-        gload(0, qa[0], qb[0]);
-        if (DEEP && n_steps > 1) gload(1, qa[1], qb[1]);
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            lstore_a(0, pass, qa[0]);
-            lstore_b(0, pass, qb[0]);
-        }
-    }
-    __syncthreads();
+    // A 64-tile that lies inside both matrices and whose K range is a whole number of steps (every
+    // small product of the Hessian inversion, nearly every one of the column loop) takes a copy of
+    // the pipeline whose steady state has no branch at all: behind a branch -- per load, or around a
+    // step's loads -- hipcc no longer knows which loads are in flight and waits for all of them, and
+    // the two-step prefetch collapses into a memory round trip per step.
+    const bool full_tile = BT == 64 && m0 + BT <= g.m && n0 + BT <= g.n && (k_hi - k_lo) % BKS == 0;
 #ifdef GQ_SG_TRACE
-    const unsigned long long t_loop = __builtin_readcyclecounter();
+    unsigned long long t_loop = 0;
 #endif
-    // one k-step; P = parity of `step`, the register set that held this step's data and is free again
-    auto k_step = [&](int step, auto par) {
-        constexpr int P = decltype(par)::value;
-        const int cur = P;
-        const bool more = step + 1 < n_steps;
-        if constexpr (DEEP) {
-            if (step + 2 < n_steps) gload(step + 2, qa[P], qb[P]);
-        } else {
-            if (more) gload(step + 1, qa[P ^ 1], qb[P ^ 1]);
-        }
-        const float *ia = smem + cur * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
-        if constexpr (DEEP) {
-            // one wave per SIMD: nobody hides the latency of the fragment reads, so all 32 of a step
-            // are issued before its first MFMA
-            float fa[BKS / 2], fb[BKS / 2];
-            const int ra = wr * 32 + li, rb = wc * 32 + li;
-#pragma unroll
-            for (int s = 0; s < BKS / 2; ++s) {
-                const int k = 2 * s + lh;
-                fa[s] = A_KM ? ia[k * BT + ra] : ia[ra * 33 + k];
-                fb[s] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
+    auto pipeline = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        // 64-tiles keep the registers of two steps in flight (indexed by step parity); 128-tiles, which
+        // run two workgroups per CU and have no registers to spare, one
+        constexpr bool DEEP = BT == 64;
+        Prefetch qa[2], qb[2];
+        auto gload = [&](int step, Prefetch &da, Prefetch &db) {
+            const int koff = step * BKS;
+    #pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                if constexpr (FULL) {
+                    da.v[pass] = *reinterpret_cast<const f32x4 *>(pa[pass]);
+                    db.v[pass] = *reinterpret_cast<const f32x4 *>(pb[pass]);
+                } else {
+                    f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+                    if (oka[pass] && ka[pass] + koff < k_hi) va = *reinterpret_cast<const f32x4 *>(pa[pass]);
+                    if (okb[pass] && kb[pass] + koff < k_hi) vb = *reinterpret_cast<const f32x4 *>(pb[pass]);
+                    da.v[pass] = va;
+                    db.v[pass] = vb;
+                }
+                pa[pass] += inc_a;
+                pb[pass] += inc_b;
             }
-#pragma unroll
-            for (int s = 0; s < BKS / 2; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sgn * fa[s], fb[s], acc[0][0], 0, 0, 0);
-                if (more && s >= BKS / 2 - 2 * NP) {
-                    const int q = s - (BKS / 2 - 2 * NP);
-                    if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
-                    else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
-                }
+        };
+        // piece `pass` of operand A or B into the LDS image of `stage`
+        auto lstore_a = [&](int stage, int pass, const Prefetch &q) {
+            float *ia = smem + stage * STAGE_FLOATS;
+            if constexpr (A_KM) {
+                constexpr int TPR = BT / 4, KPP = 256 / TPR;
+                *reinterpret_cast<f32x4 *>(ia + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
+            } else {
+                float *d = ia + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
+                d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < BKS / 2; ++s) {
-                const int k = 2 * s + lh;
-                float fa[WB], fb[WB];
-#pragma unroll
-                for (int u = 0; u < WB; ++u) {
-                    const int ra = (wr * WB + u) * 32 + li, rb = (wc * WB + u) * 32 + li;
-                    fa[u] = sgn * (A_KM ? ia[k * BT + ra] : ia[ra * 33 + k]);
-                    fb[u] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
-                }
-#pragma unroll
-                for (int a = 0; a < WB; ++a)
-#pragma unroll
-                    for (int b = 0; b < WB; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
-                // the next step's pieces go to the other LDS stage one at a time in the second half of
-                // the step, not in a burst before the barrier
-                if (more && s >= BKS / 2 - 2 * NP) {
-                    const int q = s - (BKS / 2 - 2 * NP);
-                    if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
-                    else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
-                }
+        };
+        auto lstore_b = [&](int stage, int pass, const Prefetch &q) {
+            float *ib = smem + stage * STAGE_FLOATS + IMG_FLOATS;
+            if constexpr (B_KN) {
+                constexpr int TPR = BT / 4, KPP = 256 / TPR;
+                *reinterpret_cast<f32x4 *>(ib + (tid / TPR + KPP * pass) * BT + (tid % TPR) * 4) = q.v[pass];
+            } else {
+                float *d = ib + ((tid >> 3) + 32 * pass) * 33 + (tid & 7) * 4;
+                d[0] = q.v[pass][0]; d[1] = q.v[pass][1]; d[2] = q.v[pass][2]; d[3] = q.v[pass][3];
+            }
+        };
+
+        if (n_steps > 0) {
+            gload(0, qa[0], qb[0]);
+            if (DEEP && n_steps > 1) gload(1, qa[1], qb[1]);
+    #pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                lstore_a(0, pass, qa[0]);
+                lstore_b(0, pass, qb[0]);
             }
         }
         __syncthreads();
+    #ifdef GQ_SG_TRACE
+        t_loop = __builtin_readcyclecounter();
+    #endif
+        // one k-step; P = parity of `step`, the register set that held this step's data and is free again
+        // STEADY: two more steps are known to follow, nothing in the step is conditional
+        auto k_step = [&](int step, auto par, auto steady_c) {
+            constexpr int P = decltype(par)::value;
+            constexpr bool STEADY = decltype(steady_c)::value;
+            const int cur = P;
+            const bool more = STEADY || step + 1 < n_steps;
+            if constexpr (DEEP) {
+                if (STEADY || step + 2 < n_steps) gload(step + 2, qa[P], qb[P]);
+            } else {
+                if (more) gload(step + 1, qa[P ^ 1], qb[P ^ 1]);
+            }
+            const float *ia = smem + cur * STAGE_FLOATS, *ib = ia + IMG_FLOATS;
+            if constexpr (DEEP) {
+                // one wave per SIMD: nobody hides the latency of the fragment reads, so all 32 of a step
+                // are issued before its first MFMA
+                float fa[BKS / 2], fb[BKS / 2];
+                const int ra = wr * 32 + li, rb = wc * 32 + li;
+    #pragma unroll
+                for (int s = 0; s < BKS / 2; ++s) {
+                    const int k = 2 * s + lh;
+                    fa[s] = A_KM ? ia[k * BT + ra] : ia[ra * 33 + k];
+                    fb[s] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
+                }
+    #pragma unroll
+                for (int s = 0; s < BKS / 2; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sgn * fa[s], fb[s], acc[0][0], 0, 0, 0);
+                    if (more && s >= BKS / 2 - 2 * NP) {
+                        const int q = s - (BKS / 2 - 2 * NP);
+                        if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
+                        else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int s = 0; s < BKS / 2; ++s) {
+                    const int k = 2 * s + lh;
+                    float fa[WB], fb[WB];
+    #pragma unroll
+                    for (int u = 0; u < WB; ++u) {
+                        const int ra = (wr * WB + u) * 32 + li, rb = (wc * WB + u) * 32 + li;
+                        fa[u] = sgn * (A_KM ? ia[k * BT + ra] : ia[ra * 33 + k]);
+                        fb[u] = B_KN ? ib[k * BT + rb] : ib[rb * 33 + k];
+                    }
+    #pragma unroll
+                    for (int a = 0; a < WB; ++a)
+    #pragma unroll
+                        for (int b = 0; b < WB; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    // the next step's pieces go to the other LDS stage one at a time in the second half of
+                    // the step, not in a burst before the barrier
+                    if (more && s >= BKS / 2 - 2 * NP) {
+                        const int q = s - (BKS / 2 - 2 * NP);
+                        if (q & 1) lstore_b(cur ^ 1, q >> 1, qb[P ^ 1]);
+                        else lstore_a(cur ^ 1, q >> 1, qa[P ^ 1]);
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        int step = 0;
+        if constexpr (FULL)   // the branch-free steady state: hipcc counts the waits of its loads exactly
+            for (; step + 3 < n_steps; step += 2) {
+                k_step(step, P0{}, std::true_type{});
+                k_step(step + 1, P1{}, std::true_type{});
+            }
+        for (; step < n_steps; step += 2) {
+            k_step(step, P0{}, std::false_type{});
+            if (step + 1 < n_steps) k_step(step + 1, P1{}, std::false_type{});
+        }
     };
-    for (int step = 0; step < n_steps; step += 2) {
-        k_step(step, std::integral_constant<int, 0>{});
-        if (step + 1 < n_steps) k_step(step + 1, std::integral_constant<int, 1>{});
+    if constexpr (BT == 64) {
+        if (full_tile) pipeline(std::true_type{});
+        else pipeline(std::false_type{});
+    } else {
+        pipeline(std::false_type{});
     }
 #ifdef GQ_SG_TRACE
     const unsigned long long t_end = __builtin_readcyclecounter();
