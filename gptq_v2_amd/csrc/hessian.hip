@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
     float *sc = x + NB * LLD;                         // [64][SLD]   product scratch
     float *tinv = sc + 64 * SLD;                      // [16][16]    inverse of the current diagonal block
     const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     LF_T0();
     {
         f32x4 v[16];   // the 16 loads of a thread in flight together
@@ -359,66 +360,43 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
     }
     if (__syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
 
-    // inverse by doubling: blocks of size s at b and b+s -> X21 = -X22 * (L21 * X11)
-    for (int s = PB; s < NB; s *= 2) {
-        const int tiles_per_dim = s / 4, tiles_per_pair = tiles_per_dim * tiles_per_dim;
-        const int n_pairs = NB / (2 * s);
-        // pass 1: T = L21 * X11  (X11 lower triangular: k >= column)
-        for (int t = tid; t < n_pairs * tiles_per_pair; t += 256) {
-            const int pair = t / tiles_per_pair, tt = t % tiles_per_pair;
-            const int ti = tt / tiles_per_dim, tj = tt % tiles_per_dim;
-            const int b = pair * 2 * s;
-            const float *l21 = a + (b + s + 4 * ti) * LLD + b;
-            const float *x11 = x + b * LLD + b + 4 * tj;
-            f32x4 acc[4] = {};
-            for (int k = 4 * tj; k < s; k += 4) {
-                f32x4 lr[4], xr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    lr[u] = lds4(l21 + u * LLD + k);
-                    xr[u] = lds4(x11 + (k + u) * LLD);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(lr[u][kk], xr[kk][v], acc[u][v]);
+    // inverse by doubling: blocks of size s at b and b+s -> X21 = -X22 * (L21 * X11), both products on
+    // 16x16 blocks of v_mfma_f32_16x16x4_f32, dealt round-robin to the four waves (lane l feeds
+    // A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15] and owns D[4 (l >> 4) + e][l & 15]);
+    // operands are read as stored: the zeros above the diagonals of X11 and X22 are multiplied
+    // through rather than skipped
+    {
+        const int l15 = tid & 15, lq = (tid & 63) >> 4;
+        for (int s = PB; s < NB; s *= 2) {
+            const int bpd = s / 16, bpp = bpd * bpd;   // 16x16 blocks per dimension / per pair
+            const int n_pairs = NB / (2 * s);
+            // pass 1: T = L21 * X11 into the scratch, pairs stacked by rows (n_pairs * s <= 64 rows)
+            for (int t = wid; t < n_pairs * bpp; t += 4) {
+                const int pair = t / bpp, tt = t % bpp, ti = tt / bpd, tj = tt % bpd;
+                const int b = pair * 2 * s;
+                const float *pl = a + (b + s + 16 * ti + l15) * LLD + b + lq;      // A[i][k] = L21[i][k]
+                const float *px = x + (b + lq) * LLD + b + 16 * tj + l15;          // B[k][j] = X11[k][j]
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < s; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pl[k], px[k * LLD], acc, 0, 0, 0);
+                float *dst = sc + (pair * s + 16 * ti + 4 * lq) * SLD + 16 * tj + l15;
+                dst[0] = acc[0]; dst[SLD] = acc[1]; dst[2 * SLD] = acc[2]; dst[3 * SLD] = acc[3];
             }
-            float *dst = sc + (pair * s + 4 * ti) * SLD + 4 * tj;   // pairs stacked by rows: n_pairs * s <= 64 rows
-#pragma unroll
-            for (int u = 0; u < 4; ++u) st4(dst + u * SLD, acc[u]);
-        }
-        __syncthreads();
-        LF_ADD(4);
-        // pass 2: X21 = -X22 * T  (X22 lower triangular: k <= row)
-        for (int t = tid; t < n_pairs * tiles_per_pair; t += 256) {
-            const int pair = t / tiles_per_pair, tt = t % tiles_per_pair;
-            const int ti = tt / tiles_per_dim, tj = tt % tiles_per_dim;
-            const int b = pair * 2 * s;
-            const float *x22 = x + (b + s + 4 * ti) * LLD + b + s;
-            const float *tm = sc + (pair * s) * SLD + 4 * tj;
-            f32x4 acc[4] = {};
-            for (int k = 0; k <= 4 * ti; k += 4) {
-                f32x4 xr[4], tr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    xr[u] = lds4(x22 + u * LLD + k);
-                    tr[u] = lds4(tm + (k + u) * SLD);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(-xr[u][kk], tr[kk][v], acc[u][v]);
+            __syncthreads();
+            LF_ADD(4);
+            // pass 2: X21 = -X22 * T
+            for (int t = wid; t < n_pairs * bpp; t += 4) {
+                const int pair = t / bpp, tt = t % bpp, ti = tt / bpd, tj = tt % bpd;
+                const int b = pair * 2 * s;
+                const float *px = x + (b + s + 16 * ti + l15) * LLD + b + s + lq;   // A[i][k] = X22[i][k]
+                const float *pt = sc + (pair * s + lq) * SLD + 16 * tj + l15;       // B[k][j] = T[k][j]
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < s; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-px[k], pt[k * SLD], acc, 0, 0, 0);
+                float *dst = x + (b + s + 16 * ti + 4 * lq) * LLD + b + 16 * tj + l15;
+                dst[0] = acc[0]; dst[LLD] = acc[1]; dst[2 * LLD] = acc[2]; dst[3 * LLD] = acc[3];
             }
-            float *dst = x + (b + s + 4 * ti) * LLD + b + 4 * tj;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) st4(dst + u * LLD, acc[u]);
+            __syncthreads();
+            LF_ADD(5);
         }
-        __syncthreads();
-        LF_ADD(5);
     }
     for (int e = tid; e < NB * (NB / 4); e += 256) {
         const int r = e >> 5, c4 = (e & 31) * 4;
