@@ -66,3 +66,29 @@ def test_bad_arguments_are_rejected_before_the_device_is_touched():
         _lib.check(-1, "x")
     with pytest.raises(_lib.GqError):
         _lib.check(-2, "x")
+
+
+def test_dropin_modules_carry_the_references_public_names():
+    """dropin/quant.py and dropin/gptq_py.py shadow the reference's modules of the same name: every
+    function and class those define at module level (quant.py:7-279, gptq_py.py:9-251) exists here."""
+    import importlib.util
+    import sys
+    drop = os.path.join(ROOT, "gptq_v2_amd", "dropin")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("dropin_" + name, os.path.join(drop, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    quant = load("quant")
+    for name in ("EPSILON", "quantize", "dequantize", "dequantize_quantized", "quantize2", "dequantize2",
+                 "dequantize2_quantized2", "Quantizer", "collate_quantizers", "construct_matrix", "construct_matrix_2",
+                 "reconstruct_nn_linear"):
+        assert hasattr(quant, name), name
+    gptq_py = load("gptq_py")
+    for name in ("HessianHook", "gptq_quant"):
+        assert hasattr(gptq_py, name), name
+    q = quant.Quantizer()
+    for name in ("find_params", "mse", "quantize", "dequantize", "dequantize_quantized"):
+        assert callable(getattr(q, name)), name

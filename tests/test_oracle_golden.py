@@ -241,3 +241,34 @@ def test_mixed_exl2_groups_are_stored_sorted():
     assert g["group_sizes"].tolist() == [64, 128, 32, 32] and g["group_bit_widths"].tolist() == [3, 4, 4, 3]
     assert g["meta_group_sizes"].tolist() == [128, 32, 64, 32]       # 4-bit groups first, larger first,
     assert g["meta_group_bit_widths"].tolist() == [4, 4, 3, 3]       # earlier first among equals
+
+
+def test_product_quantizer_mirror_matches_reference_on_cpu_tensors():
+    """quant.Quantizer of the product is plain tensor arithmetic on whatever device its inputs live
+    on (the fused GPU path does not go through it): on CPU tensors it reproduces the reference's
+    find_params / mse outputs bit for bit, EXL2 scales included."""
+    from gptq_v2_amd import quant as pq
+    g = load_golden("f9_grid_options")
+    w = t(g["w"])
+    for bits, sbw, mse in ((4, 4, False), (3, 4, True), (4, None, True), (4, 6, True)):
+        tag = f"b{bits}_s{sbw}_{'mse' if mse else 'nomse'}"
+        q = pq.Quantizer()
+        q.find_params(w, bit_width=torch.tensor(bits), sym=False,
+                      scale_bit_width=None if sbw is None else torch.tensor(sbw))
+        if mse:
+            q.mse(w)
+        assert torch.equal(q.scale, t(g[f"scale_{tag}"])), tag
+        assert torch.equal(q.qzero, t(g[f"qzero_{tag}"])), tag
+        if sbw is not None:
+            assert torch.equal(q.qscale, t(g[f"qscale_{tag}"])), tag
+            assert torch.equal(q.sscale, t(g[f"sscale_{tag}"])), tag
+    g3 = load_golden("f3_find_params")
+    w3 = t(g3["w"])
+    for bits in (2, 3, 4, 8):
+        for sym in (False, True):
+            tag = f"b{bits}_{'sym' if sym else 'asym'}"
+            q = pq.Quantizer()
+            q.find_params(w3, bit_width=torch.tensor(bits), sym=sym)
+            assert torch.equal(q.scale, t(g3[f"scale_{tag}"])), tag
+            assert torch.equal(q.quantize(w3), t(g3[f"q_{tag}"])), tag
+            assert torch.equal(q.dequantize_quantized(w3), t(g3[f"dq_{tag}"])), tag
