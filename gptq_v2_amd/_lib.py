@@ -54,6 +54,8 @@ SIGNATURES = {
     "gq_permute_columns": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gq_w4a16_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_void_p]),
+    "gq_w4a16_gemm_dt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                 c_int, c_int, c_void_p]),
 }
 
 _lib = None
@@ -69,7 +71,7 @@ def load() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: the HIP extension is required (build it with "
-                f"`python -m gptq_v2_amd.build`); there is no CPU fallback")
+                f"`python gptq_v2_amd/build.py`); there is no CPU fallback")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

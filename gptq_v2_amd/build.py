@@ -1,4 +1,5 @@
-"""Builds gptq_v2_amd/lib/libgptq_amd.so (hipcc, gfx950 only).  `python -m gptq_v2_amd.build`."""
+"""Builds gptq_v2_amd/lib/libgptq_amd.so (hipcc, gfx950 only).  Run as a script,
+`python gptq_v2_amd/build.py`: importing the package needs the library this produces."""
 import os
 import shutil
 import subprocess

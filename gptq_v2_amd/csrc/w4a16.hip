@@ -138,6 +138,32 @@ __device__ __forceinline__ void store_w(const WRegs &w, char *lds_b, int tid)
     }
 }
 
+// bf16 form of store_w.  A nibble OR-ed into 0x4300 is the bf16 number 128 + q exactly; widened to
+// fp32 (a 16-bit shift), 128 + z is subtracted exactly, the product with the scale is exact in fp32
+// (two 8-bit significands) and is rounded to bf16 once -- the rounding of the reference's
+// (int16 q - int16 z) * bf16 scale.
+__device__ __forceinline__ void store_w_bf16(const WRegs &w, char *lds_b, int tid)
+{
+    const int row = tid >> 1, half = tid & 1;
+    const float s = __uint_as_float(w.s_raw << 16);
+    const float zb = 128.0f + (float)w.z_raw;
+#pragma unroll
+    for (int wi = 0; wi < 4; ++wi) {
+        const unsigned word = w.q[wi];
+        u32x4 out;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned bits = ((word >> (4 * p)) & 0x000F000Fu) | 0x43004300u;   // bf16 pair (128 + v0, 128 + v1)
+            const float v0 = __fmul_rn(__fsub_rn(__uint_as_float(bits << 16), zb), s);
+            const float v1 = __fmul_rn(__fsub_rn(__uint_as_float(bits & 0xffff0000u), zb), s);
+            const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v0), hi = __builtin_bit_cast(unsigned short, (__bf16)v1);
+            out[p] = lo | (hi << 16);
+        }
+        const int chunk = (half * 4 + wi) ^ ((row >> 1) & 7);
+        *reinterpret_cast<u32x4 *>(lds_b + row * 128 + chunk * 16) = out;
+    }
+}
+
 // one quarter of store_w: the 8 values of word `wi`, placed between MFMA groups by the 256-tile kernel
 template <int WI>
 __device__ __forceinline__ void store_w_part(const WRegs &w, char *lds_b, int tid)
@@ -159,6 +185,8 @@ __device__ __forceinline__ void store_w_part(const WRegs &w, char *lds_b, int ti
     *reinterpret_cast<u32x4 *>(lds_b + row * 128 + chunk * 16) = out;
 }
 
+// DT: GQ_F16 or GQ_BF16 -- the type of x, y and the scales, and of the MFMA operands.
+template <int DT>
 __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
                                                     const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
                                                     const uint8_t *__restrict__ zero, int64_t m_total, int64_t r_total,
@@ -205,7 +233,11 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
     WCursor wcsr = w_cursor(qw, scale, zero, r_total, group_size, n0, tid);
     stage_x(x, c_total, m_total, m0, 0, smem, wave, lane);
     load_w(wregs, wcsr);
-    store_w(wregs, smem + W_OP_BYTES, tid);
+    auto expand = [&](char *lds_b) {
+        if constexpr (DT == GQ_F16) store_w(wregs, lds_b, tid);
+        else store_w_bf16(wregs, lds_b, tid);
+    };
+    expand(smem + W_OP_BYTES);
 
     auto step = [&](auto cur_c, int kt) {
         constexpr int cur = decltype(cur_c)::value;
@@ -229,12 +261,17 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a]),
-                                                                       __builtin_bit_cast(f16x8, fb[b]), acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    if constexpr (DT == GQ_F16)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a]),
+                                                                           __builtin_bit_cast(f16x8, fb[b]), acc[a][b], 0, 0, 0);
+                    else
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
+                                                                            __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_w(wregs, smem + (cur ^ 1) * W_STAGE_BYTES + W_OP_BYTES, tid);
+        if (more) expand(smem + (cur ^ 1) * W_STAGE_BYTES + W_OP_BYTES);
     };
     int kt = 0;
     for (; kt + 1 < n_ktiles; kt += 2) {
@@ -251,8 +288,10 @@ __global__ __launch_bounds__(256) void w4a16_kernel(unsigned short *__restrict__
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int64_t col = n0 + (wc * 2 + b) * 32 + li;
-                if (row < m_total && col < r_total)
-                    y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
+                if (row < m_total && col < r_total) {
+                    if constexpr (DT == GQ_F16) y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
+                    else y[row * r_total + col] = __builtin_bit_cast(unsigned short, (__bf16)acc[a][b][e]);
+                }
             }
 }
 
@@ -688,24 +727,28 @@ extern "C" int gq_debug_w4_trace(unsigned long long *buf)
 }
 #endif
 
-extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
-                             const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size, gq_stream_t stream)
+namespace {
+
+int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const void *scale, const uint8_t *qzero, int64_t m,
+                 int64_t r, int64_t c, int group_size, int dtype, gq_stream_t stream, const char *who)
 {
-    GQ_REQUIRE(y && x && qweight_packed && scale && qzero, "gq_w4a16_gemm: NULL pointer");
-    GQ_REQUIRE(m >= 0 && r > 0 && c > 0, "gq_w4a16_gemm: bad shape");
-    GQ_REQUIRE(c % WK == 0, "gq_w4a16_gemm: in_features %lld must be a multiple of %d", (long long)c, WK);
+    GQ_REQUIRE(y && x && qweight_packed && scale && qzero, "%s: NULL pointer", who);
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: bad dtype %d", who, dtype);
+    GQ_REQUIRE(m >= 0 && r > 0 && c > 0, "%s: bad shape", who);
+    GQ_REQUIRE(c % WK == 0, "%s: in_features %lld must be a multiple of %d", who, (long long)c, WK);
     GQ_REQUIRE(group_size >= 32 && group_size % 32 == 0 && c % group_size == 0,
-               "gq_w4a16_gemm: group size %d must be a multiple of 32 dividing in_features", group_size);
-    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)qweight_packed | (uintptr_t)y) & 15) == 0, "gq_w4a16_gemm: pointers must be 16-byte aligned");
+               "%s: group size %d must be a multiple of 32 dividing in_features", who, group_size);
+    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)qweight_packed | (uintptr_t)y) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
     if (m == 0) return GQ_OK;
     static const int forced = [] {   // experiments: GQ_W4_VARIANT=128 / 256 forces a tile size
         const char *e = getenv("GQ_W4_VARIANT");
         return e ? atoi(e) : 0;
     }();
     // 256-tiles unless they would occupy at most half of the chip's 256 CUs: four times as many
-    // 128-tiles then finish sooner (measured at M = 2048: 717 against 642 TFLOP/s for 4096 x 4096)
+    // 128-tiles then finish sooner (measured at M = 2048: 717 against 642 TFLOP/s for 4096 x 4096).
+    // bf16 runs on the 128-tile kernel.
     const bool few_tiles = gq_cdiv(m, W2T) * gq_cdiv(r, W2T) <= 128;
-    if (m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
+    if (dtype == GQ_F16 && m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
         const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, W2T);
         const int n_blocks = tiles_m * tiles_n;
         GQ_HIP(hipFuncSetAttribute((const void *)w4a16_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
@@ -717,10 +760,26 @@ extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_pac
     }
     const int tiles_m = (int)gq_cdiv(m, WT), tiles_n = (int)gq_cdiv(r, WT);
     const int n_blocks = tiles_m * tiles_n;
-    GQ_HIP(hipFuncSetAttribute((const void *)w4a16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
-    hipLaunchKernelGGL(w4a16_kernel, dim3(n_blocks), dim3(256), W_LDS, (hipStream_t)stream, (unsigned short *)y,
+    auto kern = dtype == GQ_F16 ? w4a16_kernel<GQ_F16> : w4a16_kernel<GQ_BF16>;
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS));
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), W_LDS, (hipStream_t)stream, (unsigned short *)y,
                        (const unsigned short *)x, qweight_packed, (const unsigned short *)scale, qzero, m, r, c, group_size,
                        tiles_n, n_blocks);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+}  // namespace
+
+extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
+                             const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size, gq_stream_t stream)
+{
+    return w4a16_launch(y, x, qweight_packed, scale, qzero, m, r, c, group_size, GQ_F16, stream, "gq_w4a16_gemm");
+}
+
+extern "C" int gq_w4a16_gemm_dt(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
+                                const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size, int dtype,
+                                gq_stream_t stream)
+{
+    return w4a16_launch(y, x, qweight_packed, scale, qzero, m, r, c, group_size, dtype, stream, "gq_w4a16_gemm_dt");
 }

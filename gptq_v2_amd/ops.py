@@ -278,11 +278,12 @@ def permute_columns(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 
 def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Tensor, qzero_t: torch.Tensor,
                group_size: int) -> torch.Tensor:
-    """x (M, C) fp16, columns in permuted order -> y (M, R) fp16.
-    qweight_packed (C/64, R, 8) int32 in the k-block layout, scale_t (G, R) fp16, qzero_t (G, R) uint8."""
-    _check(x, "x", torch.float16, 2)
+    """x (M, C) fp16 or bf16, columns in permuted order -> y (M, R) of the same type.
+    qweight_packed (C/64, R, 8) int32 in the k-block layout, scale_t (G, R) of x's type, qzero_t (G, R) uint8."""
+    _check(x, "x", None, 2)
+    code = _dtype_code(x)
     _check(qweight_packed, "qweight_packed", torch.int32, 3)
-    _check(scale_t, "scale_t", torch.float16, 2)
+    _check(scale_t, "scale_t", x.dtype, 2)
     _check(qzero_t, "qzero_t", torch.uint8, 2)
     scale, qzero = scale_t, qzero_t
     m, c = x.shape
@@ -290,9 +291,13 @@ def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Ten
     if (c % 64 or qweight_packed.shape[0] * 64 != c or qweight_packed.shape[2] != 8 or group_size <= 0
             or c % group_size or scale.shape != (c // group_size, r) or qzero.shape != scale.shape):
         raise ValueError("w4a16_gemm: inconsistent shapes")
-    y = torch.empty(m, r, dtype=torch.float16, device=x.device)
+    y = torch.empty(m, r, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().gq_w4a16_gemm(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c, int(group_size),
-                                       _stream(x))
+        if code == GQ_F16:
+            rc = _lib.load().gq_w4a16_gemm(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c, int(group_size),
+                                           _stream(x))
+        else:
+            rc = _lib.load().gq_w4a16_gemm_dt(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c,
+                                              int(group_size), code, _stream(x))
     _lib.check(rc, "gq_w4a16_gemm")
     return y

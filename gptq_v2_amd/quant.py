@@ -207,13 +207,17 @@ class QuantLinear(nn.Module):
     W4A16 dequant-GEMM (activations gathered into act-order first when the layer has one).
 
     Packed state, laid out so that a GEMM tile reads contiguous memory: ``qweight`` int32
-    (C/64, R, 8) (pair-interleaved nibbles, k-block major), ``scales`` fp16 (G, R), ``qzeros`` uint8
+    (C/64, R, 8) (pair-interleaved nibbles, k-block major), ``scales`` fp16 or bf16 (G, R), ``qzeros`` uint8
     (G, R), ``perm`` int32 (C) or None.
     ``unpack`` returns the original one-value-per-byte ``quant_meta`` tensors bit for bit.
     """
 
-    def __init__(self, in_features: int, out_features: int, group_size: int = 128, bits: int = 4):
+    def __init__(self, in_features: int, out_features: int, group_size: int = 128, bits: int = 4,
+                 dtype: torch.dtype = torch.float16):
         super().__init__()
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError("QuantLinear works in float16 or bfloat16")
+        self.dtype = dtype
         if bits != 4:
             raise NotImplementedError("QuantLinear.forward is implemented for 4-bit weights")
         self.in_features, self.out_features = in_features, out_features
@@ -230,7 +234,8 @@ class QuantLinear(nn.Module):
         bits = set(_group_list(quant_meta["group_bit_widths"]))
         if len(set(gs)) != 1 or len(bits) != 1:
             raise NotImplementedError("QuantLinear needs one group size and one bit width")
-        layer = cls(c, r, gs[0], bits.pop())
+        sdt = quant_meta["scale"].dtype   # the model's 16-bit type (gptq_py.py:218)
+        layer = cls(c, r, gs[0], bits.pop(), sdt if sdt in (torch.float16, torch.bfloat16) else torch.float16)
         layer.pack(quant_meta, device)
         return layer
 
@@ -243,7 +248,7 @@ class QuantLinear(nn.Module):
         if self.in_features % 64:
             raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
         self.qweight = ops.pack_rows(q, self.bits, ops.PACK_W4_KBLOCK)
-        self.scales = meta_scale(quant_meta, torch.float16, device).t().contiguous()
+        self.scales = meta_scale(quant_meta, self.dtype, device).t().contiguous()
         self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
         perm_inv = quant_meta.get("perm_inv")
         if perm_inv is None:
@@ -279,8 +284,8 @@ class QuantLinear(nn.Module):
         """x[..., perm]: the activation gather of act-order.  Layers quantised against the same
         Hessian (q/k/v, gate/up) share ``perm``, so their caller can do this once and use
         ``forward_permuted`` on each of them."""
-        if x.dtype != torch.float16:
-            raise NotImplementedError("QuantLinear takes float16 activations")
+        if x.dtype != self.dtype:
+            raise NotImplementedError(f"this QuantLinear takes {self.dtype} activations, got {x.dtype}")
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         if self.perm is not None:
@@ -291,8 +296,8 @@ class QuantLinear(nn.Module):
     def forward_permuted(self, x_permuted: torch.Tensor) -> torch.Tensor:
         shape = x_permuted.shape
         x2 = x_permuted.reshape(-1, shape[-1])
-        if x2.dtype != torch.float16:
-            raise NotImplementedError("QuantLinear takes float16 activations")
+        if x2.dtype != self.dtype:
+            raise NotImplementedError(f"this QuantLinear takes {self.dtype} activations, got {x2.dtype}")
         y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size)
         return y.reshape(*shape[:-1], self.out_features)
 

@@ -205,6 +205,14 @@ int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const 
                   const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size,
                   gq_stream_t stream);
 
+/* The same product for x, y and scale_t of type `dtype` (GQ_F16 or GQ_BF16).  bf16: W[r][k] is
+ * (q - z) * scale rounded once to bf16, as the reference's reconstruction of a bf16 model computes
+ * it (quant.py:30 with the operand types of quant.py:263-272), fp32 accumulation, bf16 output.
+ * Fills the same slot as gq_w4a16_gemm (llama.py:172-177) for models held in bfloat16. */
+int gq_w4a16_gemm_dt(void *y, const void *x, const uint32_t *qweight_packed, const void *scale_t,
+                     const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size,
+                     int dtype, gq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,9 +22,9 @@ def _declared():
 def test_header_declares_what_we_think():
     names = _declared()
     for must in ("gq_xtx_accumulate", "gq_hessian_invert", "gq_quantize_range", "gq_quantize_layer",
-                 "gq_quantize_layer_ex", "gq_quantize_rtn", "gq_dequantize", "gq_pack_rows", "gq_w4a16_gemm"):
+                 "gq_quantize_layer_ex", "gq_quantize_rtn", "gq_dequantize", "gq_pack_rows", "gq_w4a16_gemm", "gq_w4a16_gemm_dt"):
         assert must in names
-    assert len(names) == 17
+    assert len(names) == 18
 
 
 def test_library_exports_every_declared_symbol():

@@ -143,3 +143,23 @@ def test_staged_walk_equals_rerun_walk(amd, gpu, pack):
     pa = float(driver.evaluate_llama(a, enc, gpu, batch_size=4))
     pb = float(driver.evaluate_llama(b, enc, gpu, batch_size=4))
     assert pa == pb
+
+
+def test_bf16_model_dense_and_packed_agree(amd, gpu):
+    """A bfloat16 model: the packed layers (bf16 W4A16 GEMM) and the dense reconstructed weights
+    hold the same bf16 values, so the two models agree to bf16 accumulation noise."""
+    from gptq_v2_amd import driver
+    model = _tiny_llama(seed=5).to(torch.bfloat16)
+    enc = torch.randint(0, 512, (8, 64), generator=torch.Generator().manual_seed(6))
+    a, b = copy.deepcopy(model), copy.deepcopy(model)
+    ra = driver.quantize_llama(a, enc, gpu, batch_size=4, pack=False)
+    rb = driver.quantize_llama(b, enc, gpu, batch_size=4, pack=True)
+    assert ra["data"]["model.layers.0.self_attn.q_proj"]["scale"].dtype == torch.bfloat16
+    assert isinstance(b.model.layers[0].mlp.down_proj, amd.QuantLinear)
+    assert b.model.layers[0].mlp.down_proj.dtype == torch.bfloat16
+    # first block's first set sees identical inputs in both runs
+    for k in ("qweight", "scale", "qzero"):
+        assert torch.equal(ra["data"]["model.layers.0.self_attn.q_proj"][k], rb["data"]["model.layers.0.self_attn.q_proj"][k])
+    pa = float(driver.evaluate_llama(a, enc, gpu, batch_size=4))
+    pb = float(driver.evaluate_llama(b, enc, gpu, batch_size=4))
+    assert pa == pytest.approx(pb, rel=0.03) and pa > 1.0

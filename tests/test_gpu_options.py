@@ -204,3 +204,29 @@ def test_option_errors(amd, gpu):
     hook.hessian = torch.ones(1, device=gpu)
     with pytest.raises(ValueError):            # blocks must cover the columns
         amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=False, gptq_block_sizes=torch.tensor([128, 64]), quant_mse=False)
+
+
+@pytest.mark.parametrize("m,r,c,gsz", [(300, 200, 256, 64), (512, 384, 512, 128), (2048, 4096, 4096, 128)])
+def test_w4a16_gemm_bf16(amd, gpu, m, r, c, gsz):
+    """bf16 activations / scales / output: the product equals x @ W^T for W = bf16((q - z) * scale)
+    (one rounding, what reconstruct_nn_linear builds for a bf16 model) to bf16 output rounding."""
+    gen = torch.Generator().manual_seed(m + r + c)
+    q = torch.randint(0, 16, (r, c), generator=gen, dtype=torch.uint8).to(gpu)
+    scale = (torch.rand(r, c // gsz, generator=gen) * 0.01 + 0.002).to(torch.bfloat16).to(gpu)
+    zero = torch.randint(0, 16, (r, c // gsz), generator=gen, dtype=torch.uint8).to(gpu)
+    x = torch.randn(m, c, generator=gen).to(torch.bfloat16).to(gpu)
+    meta = {"qweight": q, "scale": scale, "qzero": zero, "qscale": None, "sscale": None, "perm_inv": None,
+            "group_sizes": torch.full([c // gsz], gsz, dtype=torch.int16), "group_bit_widths": torch.full([c // gsz], 4, dtype=torch.uint8)}
+    w = amd.reconstruct_nn_linear(meta, dtype=torch.bfloat16, device=gpu).weight.data
+    # the dense weight itself: (int q - int z) * scale evaluated in bf16
+    want_w = ((q.int() - zero.int().repeat_interleave(gsz, dim=1)).to(torch.bfloat16) * scale.repeat_interleave(gsz, dim=1))
+    assert torch.equal(w, want_w)
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    assert layer.dtype == torch.bfloat16 and layer.scales.dtype == torch.bfloat16
+    y = layer(x)
+    assert y.dtype == torch.bfloat16 and y.shape == (m, r)
+    ref = x.double() @ w.double().t()
+    err = (y.double() - ref).abs().max()
+    assert err <= 2 ** -7 * ref.abs().max() + 1e-3, (float(err), float(ref.abs().max()))
+    with pytest.raises(NotImplementedError):
+        layer(x.half())
