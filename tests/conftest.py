@@ -1,4 +1,5 @@
 import os
+import shutil
 import subprocess
 import sys
 
@@ -17,6 +18,11 @@ def pytest_configure(config):
     # The CPU oracle is test infrastructure; build it if this checkout has no copy yet.
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    # The product library is built in-tree by __graft_entry__.build(); a checkout that has not run it
+    # yet gets it here if hipcc is around (the tests themselves never build anything on a GPU box).
+    lib = os.path.join(ROOT, "gptq_v2_amd", "lib", "libgptq_amd.so")
+    if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "gptq_v2_amd", "build.py")])
 
 
 def load_golden(name):
