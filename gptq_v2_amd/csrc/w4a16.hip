@@ -348,6 +348,50 @@ __device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConst &d, u
     return out;
 }
 
+// bf16: q as fp32 (byte conversions of the nibble-split word), one fma per value with -z * s as the
+// addend -- q * s and z * s are exact in fp32 (4 or 8 bits times 8 bits) and so is their difference
+// (q - z) * s, which is then rounded to bf16 once, the rounding of the reference's
+// (int16 q - int16 z) * bf16 scale.  Two values per v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DeqConstB {
+    f32x2 s2;
+    f32x2 nzs2;
+};
+
+template <int DT>
+__device__ __forceinline__ auto deq_const_dt(const WRegs &w)
+{
+    if constexpr (DT == GQ_F16) {
+        return deq_const(w);
+    } else {
+        DeqConstB d;
+        const float s = __uint_as_float(w.s_raw << 16);
+        const float nzs = -(float)w.z_raw * s;   // exact
+        d.s2 = f32x2{s, s};
+        d.nzs2 = f32x2{nzs, nzs};
+        return d;
+    }
+}
+
+__device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConstB &d, unsigned, unsigned)
+{
+    const unsigned even = word & 0x0F0F0F0Fu;          // nibbles 0, 2, 4, 6 in bytes 0..3
+    const unsigned odd = (word >> 4) & 0x0F0F0F0Fu;    // nibbles 1, 3, 5, 7
+    u32x4 out;
+    // out[p] holds the values of nibbles p and p + 4
+    auto pair = [&](unsigned src, int byte_lo) {
+        f32x2 q{(float)((src >> (8 * byte_lo)) & 0xffu), (float)((src >> (8 * (byte_lo + 2))) & 0xffu)};
+        const f32x2 v = __builtin_elementwise_fma(q, d.s2, d.nzs2);
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]), hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+        return lo | (hi << 16);
+    };
+    out[0] = pair(even, 0);
+    out[1] = pair(odd, 0);
+    out[2] = pair(even, 1);
+    out[3] = pair(odd, 1);
+    return out;
+}
+
 // Wave-uniform read position of the 256-row tile in the packed weights (group sizes that are
 // multiples of the 64-deep k-step: all 64 values of a row's k-step share one group).  Lives in
 // SGPRs; each thread adds its own constant offsets.
@@ -408,6 +452,7 @@ __device__ __forceinline__ void stage_x2(const unsigned short *__restrict__ x, i
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
                                                         const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
                                                         const uint8_t *__restrict__ zero, int64_t m_total, int64_t r_total,
@@ -492,7 +537,8 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     unsigned magic0 = 0x64006400u, magic1 = 0x54005400u;
     asm volatile("" : "+v"(magic0), "+v"(magic1));   // keep them in VGPRs (operands of v_and_or_b32)
     const int wrow = tid >> 1, whalf = tid & 1;
-    auto store_part = [&](const WRegs &w, const DeqConst &d, int wi, char *lds_b) {
+    using DQ = std::conditional_t<DT == GQ_F16, DeqConst, DeqConstB>;
+    auto store_part = [&](const WRegs &w, const DQ &d, int wi, char *lds_b) {
         const u32x4 out = expand_word(w.q[wi], d, magic0, magic1);
         const int chunk = (whalf * 4 + wi) ^ ((wrow >> 1) & 7);
         *reinterpret_cast<u32x4 *>(lds_b + wrow * 128 + chunk * 16) = out;
@@ -502,7 +548,7 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     load_w2(wcur);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcur.q), "+v"(wcur.s_raw), "+v"(wcur.z_raw)::"memory");
     {
-        const DeqConst d = deq_const(wcur);
+        const DQ d = deq_const_dt<DT>(wcur);
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi) store_part(wcur, d, wi, smem + W2_OP_BYTES);
     }
@@ -530,8 +576,12 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[slot][a]),
-                                                                   __builtin_bit_cast(f16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
+                if constexpr (DT == GQ_F16)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[slot][a]),
+                                                                       __builtin_bit_cast(f16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
+                else
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[slot][a]),
+                                                                        __builtin_bit_cast(bf16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
                 if (b == 1 && (a == 0 || a == 2)) {
                     __builtin_amdgcn_sched_barrier(0);
                     between(a >> 1);
@@ -580,9 +630,9 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         read_frags(1, sb, 1);
         GQ_TR(10);
         __builtin_amdgcn_sched_barrier(0);   // reads first: their latency runs under the expansion
-        DeqConst dq;
+        DQ dq;
         if constexpr (MORE) {
-            dq = deq_const(wuse);
+            dq = deq_const_dt<DT>(wuse);
             store_part(wuse, dq, 0, nb);
             store_part(wuse, dq, 1, nb);
         }
@@ -704,8 +754,10 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = m0 + (wr * 4 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int64_t col = n0 + (wc * 2 + b) * 32 + li;
-                if (row < m_total && col < r_total)
-                    y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
+                if (row < m_total && col < r_total) {
+                    if constexpr (DT == GQ_F16) y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
+                    else y[row * r_total + col] = __builtin_bit_cast(unsigned short, (__bf16)acc[a][b][e]);
+                }
             }
 #ifdef GQ_W4_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -746,13 +798,13 @@ int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const v
     }();
     // 256-tiles unless they would occupy at most half of the chip's 256 CUs: four times as many
     // 128-tiles then finish sooner (measured at M = 2048: 717 against 642 TFLOP/s for 4096 x 4096).
-    // bf16 runs on the 128-tile kernel.
     const bool few_tiles = gq_cdiv(m, W2T) * gq_cdiv(r, W2T) <= 128;
-    if (dtype == GQ_F16 && m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
+    if (m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
         const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, W2T);
         const int n_blocks = tiles_m * tiles_n;
-        GQ_HIP(hipFuncSetAttribute((const void *)w4a16_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
-        hipLaunchKernelGGL(w4a16_256_kernel, dim3(n_blocks), dim3(512), W2_LDS, (hipStream_t)stream, (unsigned short *)y,
+        auto kern2 = dtype == GQ_F16 ? w4a16_256_kernel<GQ_F16> : w4a16_256_kernel<GQ_BF16>;
+        GQ_HIP(hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+        hipLaunchKernelGGL(kern2, dim3(n_blocks), dim3(512), W2_LDS, (hipStream_t)stream, (unsigned short *)y,
                            (const unsigned short *)x, qweight_packed, (const unsigned short *)scale, qzero, m, r, c,
                            group_size, tiles_n, n_blocks);
         GQ_LAUNCH_CHECK();

@@ -206,7 +206,8 @@ def test_option_errors(amd, gpu):
         amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=False, gptq_block_sizes=torch.tensor([128, 64]), quant_mse=False)
 
 
-@pytest.mark.parametrize("m,r,c,gsz", [(300, 200, 256, 64), (512, 384, 512, 128), (2048, 4096, 4096, 128)])
+@pytest.mark.parametrize("m,r,c,gsz", [(300, 200, 256, 64), (512, 384, 512, 128), (2048, 4096, 4096, 128),
+                                       (4200, 4352, 512, 64), (4352, 4100, 1024, 128)])
 def test_w4a16_gemm_bf16(amd, gpu, m, r, c, gsz):
     """bf16 activations / scales / output: the product equals x @ W^T for W = bf16((q - z) * scale)
     (one rounding, what reconstruct_nn_linear builds for a bf16 model) to bf16 output rounding."""
@@ -230,3 +231,22 @@ def test_w4a16_gemm_bf16(amd, gpu, m, r, c, gsz):
     assert err <= 2 ** -7 * ref.abs().max() + 1e-3, (float(err), float(ref.abs().max()))
     with pytest.raises(NotImplementedError):
         layer(x.half())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,r,gsz", [(512, 320, 64), (4352, 4352, 128)])
+def test_w4a16_gemm_identity_is_dequantised_weight(amd, gpu, dtype, n, r, gsz):
+    """x = identity: every output is one dequantised weight passed through the accumulator unchanged,
+    so the product equals the dense reconstruct_nn_linear weight bit for bit -- the in-kernel
+    expansion of the nibbles rounds as the reference's (q - z) * scale in the tensor dtype does.
+    The larger case runs on the 256-tile kernel, the smaller on the 128-tile one."""
+    gen = torch.Generator().manual_seed(n + r)
+    q = torch.randint(0, 16, (r, n), generator=gen, dtype=torch.uint8).to(gpu)
+    scale = (torch.rand(r, n // gsz, generator=gen) * 0.01 + 0.002).to(dtype).to(gpu)
+    zero = torch.randint(0, 16, (r, n // gsz), generator=gen, dtype=torch.uint8).to(gpu)
+    meta = {"qweight": q, "scale": scale, "qzero": zero, "qscale": None, "sscale": None, "perm_inv": None,
+            "group_sizes": torch.full([n // gsz], gsz, dtype=torch.int16), "group_bit_widths": torch.full([n // gsz], 4, dtype=torch.uint8)}
+    w = amd.reconstruct_nn_linear(meta, dtype=dtype, device=gpu).weight.data
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    y = layer(torch.eye(n, dtype=dtype, device=gpu))
+    assert torch.equal(y, w.t())
