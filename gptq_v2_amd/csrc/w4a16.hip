@@ -138,51 +138,56 @@ __device__ __forceinline__ void store_w(const WRegs &w, char *lds_b, int tid)
     }
 }
 
-// bf16 form of store_w.  A nibble OR-ed into 0x4300 is the bf16 number 128 + q exactly; widened to
-// fp32 (a 16-bit shift), 128 + z is subtracted exactly, the product with the scale is exact in fp32
-// (two 8-bit significands) and is rounded to bf16 once -- the rounding of the reference's
-// (int16 q - int16 z) * bf16 scale.
+// bf16: q as fp32 (byte conversions of the nibble-split word), one fma per value with -z * s as the
+// addend -- q * s and z * s are exact in fp32 (4 or 8 bits times 8 bits) and so is their difference
+// (q - z) * s, which is then rounded to bf16 once, the rounding of the reference's
+// (int16 q - int16 z) * bf16 scale.  Two values per v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DeqConstB {
+    f32x2 s2;
+    f32x2 nzs2;
+};
+
+__device__ __forceinline__ DeqConstB deq_const_bf16(const WRegs &w)
+{
+    DeqConstB d;
+    const float s = __uint_as_float(w.s_raw << 16);
+    const float nzs = -(float)w.z_raw * s;   // exact
+    d.s2 = f32x2{s, s};
+    d.nzs2 = f32x2{nzs, nzs};
+    return d;
+}
+
+__device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConstB &d, unsigned, unsigned)
+{
+    const unsigned even = word & 0x0F0F0F0Fu;          // nibbles 0, 2, 4, 6 in bytes 0..3
+    const unsigned odd = (word >> 4) & 0x0F0F0F0Fu;    // nibbles 1, 3, 5, 7
+    u32x4 out;
+    // out[p] holds the values of nibbles p and p + 4
+    auto pair = [&](unsigned src, int byte_lo) {
+        f32x2 q{(float)((src >> (8 * byte_lo)) & 0xffu), (float)((src >> (8 * (byte_lo + 2))) & 0xffu)};
+        const f32x2 v = __builtin_elementwise_fma(q, d.s2, d.nzs2);
+        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]), hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
+        return lo | (hi << 16);
+    };
+    out[0] = pair(even, 0);
+    out[1] = pair(odd, 0);
+    out[2] = pair(even, 1);
+    out[3] = pair(odd, 1);
+    return out;
+}
+
+// bf16 form of store_w
 __device__ __forceinline__ void store_w_bf16(const WRegs &w, char *lds_b, int tid)
 {
     const int row = tid >> 1, half = tid & 1;
-    const float s = __uint_as_float(w.s_raw << 16);
-    const float zb = 128.0f + (float)w.z_raw;
+    const DeqConstB d = deq_const_bf16(w);
 #pragma unroll
     for (int wi = 0; wi < 4; ++wi) {
-        const unsigned word = w.q[wi];
-        u32x4 out;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned bits = ((word >> (4 * p)) & 0x000F000Fu) | 0x43004300u;   // bf16 pair (128 + v0, 128 + v1)
-            const float v0 = __fmul_rn(__fsub_rn(__uint_as_float(bits << 16), zb), s);
-            const float v1 = __fmul_rn(__fsub_rn(__uint_as_float(bits & 0xffff0000u), zb), s);
-            const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v0), hi = __builtin_bit_cast(unsigned short, (__bf16)v1);
-            out[p] = lo | (hi << 16);
-        }
+        const u32x4 out = expand_word(w.q[wi], d, 0u, 0u);
         const int chunk = (half * 4 + wi) ^ ((row >> 1) & 7);
         *reinterpret_cast<u32x4 *>(lds_b + row * 128 + chunk * 16) = out;
     }
-}
-
-// one quarter of store_w: the 8 values of word `wi`, placed between MFMA groups by the 256-tile kernel
-template <int WI>
-__device__ __forceinline__ void store_w_part(const WRegs &w, char *lds_b, int tid)
-{
-    const int row = tid >> 1, half = tid & 1;
-    f16x2 s2, z2;
-    w_scale_zero(w, s2, z2);
-    const unsigned word = w.q[WI];
-    u32x4 out;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const unsigned bits = ((word >> (4 * p)) & 0x000F000Fu) | 0x64006400u;
-        f16x2 v = __builtin_bit_cast(f16x2, bits);
-        v = v - z2;
-        v = v * s2;
-        out[p] = __builtin_bit_cast(unsigned, v);
-    }
-    const int chunk = (half * 4 + WI) ^ ((row >> 1) & 7);
-    *reinterpret_cast<u32x4 *>(lds_b + row * 128 + chunk * 16) = out;
 }
 
 // DT: GQ_F16 or GQ_BF16 -- the type of x, y and the scales, and of the MFMA operands.
@@ -321,6 +326,13 @@ __device__ __forceinline__ DeqConst deq_const(const WRegs &w)
     return d;
 }
 
+template <int DT>
+__device__ __forceinline__ auto deq_const_dt(const WRegs &w)
+{
+    if constexpr (DT == GQ_F16) return deq_const(w);
+    else return deq_const_bf16(w);
+}
+
 // (x & mask) | magic in one instruction; the mask rides in an SGPR (one literal per VOP3 at most)
 __device__ __forceinline__ unsigned and_or_b32(unsigned x, unsigned mask, unsigned magic)
 {
@@ -345,50 +357,6 @@ __device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConst &d, u
     out[1] = __builtin_bit_cast(unsigned, v1 * d.s2);
     out[2] = __builtin_bit_cast(unsigned, v2 * d.s2);
     out[3] = __builtin_bit_cast(unsigned, v3 * d.s2);
-    return out;
-}
-
-// bf16: q as fp32 (byte conversions of the nibble-split word), one fma per value with -z * s as the
-// addend -- q * s and z * s are exact in fp32 (4 or 8 bits times 8 bits) and so is their difference
-// (q - z) * s, which is then rounded to bf16 once, the rounding of the reference's
-// (int16 q - int16 z) * bf16 scale.  Two values per v_pk_fma_f32.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct DeqConstB {
-    f32x2 s2;
-    f32x2 nzs2;
-};
-
-template <int DT>
-__device__ __forceinline__ auto deq_const_dt(const WRegs &w)
-{
-    if constexpr (DT == GQ_F16) {
-        return deq_const(w);
-    } else {
-        DeqConstB d;
-        const float s = __uint_as_float(w.s_raw << 16);
-        const float nzs = -(float)w.z_raw * s;   // exact
-        d.s2 = f32x2{s, s};
-        d.nzs2 = f32x2{nzs, nzs};
-        return d;
-    }
-}
-
-__device__ __forceinline__ u32x4 expand_word(unsigned word, const DeqConstB &d, unsigned, unsigned)
-{
-    const unsigned even = word & 0x0F0F0F0Fu;          // nibbles 0, 2, 4, 6 in bytes 0..3
-    const unsigned odd = (word >> 4) & 0x0F0F0F0Fu;    // nibbles 1, 3, 5, 7
-    u32x4 out;
-    // out[p] holds the values of nibbles p and p + 4
-    auto pair = [&](unsigned src, int byte_lo) {
-        f32x2 q{(float)((src >> (8 * byte_lo)) & 0xffu), (float)((src >> (8 * (byte_lo + 2))) & 0xffu)};
-        const f32x2 v = __builtin_elementwise_fma(q, d.s2, d.nzs2);
-        const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)v[0]), hi = __builtin_bit_cast(unsigned short, (__bf16)v[1]);
-        return lo | (hi << 16);
-    };
-    out[0] = pair(even, 0);
-    out[1] = pair(odd, 0);
-    out[2] = pair(even, 1);
-    out[3] = pair(odd, 1);
     return out;
 }
 
