@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "xtx_traffic.json"),
                     help="per-launch HBM bytes of the XtX kernel from a rocprofv3 --pmc run, if present")
+    ap.add_argument("--w4-traffic-json", default=os.path.join(ROOT, "profiles", "w4a16_traffic.json"),
+                    help="per-launch HBM bytes of the W4A16 kernel from a rocprofv3 --pmc run, if present")
     return ap.parse_args()
 
 
@@ -249,22 +251,26 @@ def main():
 
     if rank == 0:
         breakdown = {n: round(p.total_ms() / max(args.steps, 1), 3) for n, p in phases.items() if p.count()}
-        # dominant kernel: the XtX MFMA kernel at C = 4096 (one launch per add_batch call)
+        def pmc_bytes(path):
+            try:
+                return json.load(open(path)).get("hbm_bytes_per_launch")
+            except Exception:
+                return None
+
+        # second kernel by share of the step: the XtX MFMA kernel at C = 4096 (one launch per add_batch call)
         px = phases["xtx_%d" % HIDDEN]
         t_call = px.total_ms() / max(px.count(), 1) * 1e-3
         tokens_call = min(args.batch, se - sb) * SEQ
         flops_call = 2.0 * tokens_call * HIDDEN * HIDDEN        # full product, as the algorithmic figure counts it
         achieved = flops_call / t_call / 1e12 if t_call > 0 else 0.0
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = pmc_bytes(args.traffic_json)
+        # dominant kernel (about half of the step's GPU time): the W4A16 GEMM of the replay, one launch
+        # per Linear and batch; flops and duration are means over the 7 Linear shapes of the block
         pw = phases["w4a16"]
         local_tokens = (se - sb) * SEQ
         w4_flops = sum(2.0 * local_tokens * r * c for c, outs in SETS for r in outs) * args.steps
         w4_tflops = w4_flops / (pw.total_ms() * 1e-3) / 1e12 if pw.count() else 0.0
+        w4_launch_ms = pw.total_ms() / max(pw.count(), 1)
         line = {
             "metric": "llama2_7b_w4g128_quantize_wallclock",
             "value": round(ms_per_step * N_BLOCKS / 1e3, 3),
@@ -286,10 +292,15 @@ def main():
             "int4_gemm_tflops": round(w4_tflops, 1),
             "int4_gemm_frac_of_f16_mfma_peak": round(w4_tflops / MFMA_F16_PEAK_TFLOPS, 4),
             "breakdown_ms_per_step": breakdown,
-            "roofline": {"kernel": "xtx256_kernel (H += X^T X, C=4096, %d tokens per launch)" % tokens_call,
-                         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "avg_launch_ms": round(t_call * 1e3, 4)},
+            "roofline": {"kernel": "w4a16_256_kernel (y = x W4^T, %d tokens per launch, mean of the 7 Linears of a block)" % tokens_call,
+                         "bound": "mfma", "achieved": round(w4_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(w4_tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                         "traffic": pmc_bytes(args.w4_traffic_json), "avg_launch_ms": round(w4_launch_ms, 4),
+                         "launches": pw.count()},
+            "roofline_xtx": {"kernel": "xtx256_kernel (H += X^T X, C=4096, %d tokens per launch)" % tokens_call,
+                             "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+                             "avg_launch_ms": round(t_call * 1e3, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -424,7 +424,7 @@ template <int DT>
 __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
                                                         const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
                                                         const uint8_t *__restrict__ zero, int64_t m_total, int64_t r_total,
-                                                        int64_t c_total, int group_size, int tiles_n, int n_blocks)
+                                                        int64_t c_total, int group_size, int tiles_n, int n_blocks, int band)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef GQ_W4_TRACE
@@ -439,7 +439,18 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         const int q = n_blocks >> 3, r = n_blocks & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int64_t m0 = (int64_t)(bid / tiles_n) * W2T, n0 = (int64_t)(bid % tiles_n) * W2T;
+    // tiles in bands of `band` tile rows, column-major inside a band: the 32 workgroups an XCD runs
+    // at a time cover band x (32 / band) tiles and share that many x panels and W tiles in its L2
+    int tm, tn;
+    {
+        const int per_band = band * tiles_n;
+        const int b = bid / per_band, within = bid - b * per_band;
+        const int tiles_m = n_blocks / tiles_n;
+        const int rows = min(band, tiles_m - b * band);
+        tn = within / rows;
+        tm = b * band + (within - tn * rows);
+    }
+    const int64_t m0 = (int64_t)tm * W2T, n0 = (int64_t)tn * W2T;
     const int n_ktiles = (int)(c_total / WK);
 
     const int wr = wave >> 2, wc = wave & 3;
@@ -770,11 +781,16 @@ int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const v
     if (m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
         const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, W2T);
         const int n_blocks = tiles_m * tiles_n;
+        static const int band_env = [] {
+            const char *e = getenv("GQ_W4_BAND");
+            return e ? atoi(e) : 0;
+        }();
+        const int band = band_env > 0 ? band_env : 2;   // memory-side reads of the 11008 x 4096 shape: -32 % against 1; run time unchanged
         auto kern2 = dtype == GQ_F16 ? w4a16_256_kernel<GQ_F16> : w4a16_256_kernel<GQ_BF16>;
         GQ_HIP(hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
         hipLaunchKernelGGL(kern2, dim3(n_blocks), dim3(512), W2_LDS, (hipStream_t)stream, (unsigned short *)y,
                            (const unsigned short *)x, qweight_packed, (const unsigned short *)scale, qzero, m, r, c,
-                           group_size, tiles_n, n_blocks);
+                           group_size, tiles_n, n_blocks, band);
         GQ_LAUNCH_CHECK();
         return GQ_OK;
     }
