@@ -205,6 +205,8 @@ def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.de
 class QuantLinear(nn.Module):
     """Packed int4 Linear: ``pack`` takes a ``quant_meta`` dict, ``forward`` runs the
     W4A16 dequant-GEMM (activations gathered into act-order first when the layer has one).
+    2- and 3-bit layers are held in the same 4-bit containers (the arithmetic (q - z) * scale is
+    the same for every width up to 4), so they cost 4 bits per weight in memory.
 
     Packed state, laid out so that a GEMM tile reads contiguous memory: ``qweight`` int32
     (C/64, R, 8) (pair-interleaved nibbles, k-block major), ``scales`` fp16 or bf16 (G, R), ``qzeros`` uint8
@@ -218,8 +220,8 @@ class QuantLinear(nn.Module):
         if dtype not in (torch.float16, torch.bfloat16):
             raise NotImplementedError("QuantLinear works in float16 or bfloat16")
         self.dtype = dtype
-        if bits != 4:
-            raise NotImplementedError("QuantLinear.forward is implemented for 4-bit weights")
+        if bits not in (2, 3, 4):
+            raise NotImplementedError("QuantLinear.forward is implemented for weights of 2 to 4 bits")
         self.in_features, self.out_features = in_features, out_features
         self.group_size, self.bits = group_size, bits
         self.register_buffer("qweight", None)
@@ -247,7 +249,9 @@ class QuantLinear(nn.Module):
             raise ValueError("quant_meta does not match this layer's shape")
         if self.in_features % 64:
             raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
-        self.qweight = ops.pack_rows(q, self.bits, ops.PACK_W4_KBLOCK)
+        if int(q.max()) >= (1 << self.bits) or int(quant_meta["qzero"].max()) >= (1 << self.bits):
+            raise ValueError(f"quant_meta holds values outside {self.bits} bits")
+        self.qweight = ops.pack_rows(q, 4, ops.PACK_W4_KBLOCK)
         self.scales = meta_scale(quant_meta, self.dtype, device).t().contiguous()
         self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
         perm_inv = quant_meta.get("perm_inv")
@@ -263,7 +267,7 @@ class QuantLinear(nn.Module):
 
     @torch.no_grad()
     def unpack(self) -> dict:
-        q = ops.unpack_rows(self.qweight, self.bits, self.in_features, ops.PACK_W4_KBLOCK)
+        q = ops.unpack_rows(self.qweight, 4, self.in_features, ops.PACK_W4_KBLOCK)
         c = self.in_features
         if self.perm is None:
             perm_inv = torch.arange(c, dtype=torch.int16, device=q.device)

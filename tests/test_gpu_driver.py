@@ -85,14 +85,17 @@ def test_quantize_tiny_llama_end_to_end(amd, oracle, gpu):
     assert abs(ppl_gptq - ppl_fp) <= abs(ppl_rtn - ppl_fp) + 1e-3 * ppl_fp
 
 
-def test_quantize_tiny_llama_packed_layers_agree_with_dense(amd, gpu):
+@pytest.mark.parametrize("bits", [4, 3])
+def test_quantize_tiny_llama_packed_layers_agree_with_dense(amd, gpu, bits):
     from gptq_v2_amd import driver
     model = _tiny_llama(seed=3)
     enc = torch.randint(0, 512, (8, 64), generator=torch.Generator().manual_seed(2))
     dense, packed = copy.deepcopy(model), copy.deepcopy(model)
-    r1 = driver.quantize_llama(dense, enc, gpu, batch_size=4)
-    r2 = driver.quantize_llama(packed, enc, gpu, batch_size=4, pack=True)
+    r1 = driver.quantize_llama(dense, enc, gpu, batch_size=4, bits=bits)
+    r2 = driver.quantize_llama(packed, enc, gpu, batch_size=4, bits=bits, pack=True)
     assert isinstance(packed.model.layers[0].mlp.down_proj, amd.QuantLinear)
+    assert packed.model.layers[0].mlp.down_proj.bits == bits
+    assert int(r2["data"]["model.layers.0.mlp.down_proj"]["qweight"].max()) == (1 << bits) - 1
     # block 0 sees identical inputs in both runs, so its first set must agree exactly; later sets see
     # activations that went through the packed GEMM (fp32 accumulation order differs from the dense one)
     for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"):

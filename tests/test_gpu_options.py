@@ -250,3 +250,29 @@ def test_w4a16_gemm_identity_is_dequantised_weight(amd, gpu, dtype, n, r, gsz):
     layer = amd.QuantLinear.from_quant_meta(meta, gpu)
     y = layer(torch.eye(n, dtype=dtype, device=gpu))
     assert torch.equal(y, w.t())
+
+
+@pytest.mark.parametrize("bits", [2, 3])
+def test_quantlinear_narrow_bit_widths(amd, gpu, bits):
+    """3- and 2-bit layers (the Llama-2-70B configuration quantises to 3 bits) run through the same
+    packed GEMM in 4-bit containers: identity input returns the dense reconstruct_nn_linear weight
+    bit for bit, unpack() returns quant_meta unchanged, values beyond the width are refused."""
+    n, r, gsz = 512, 320, 128
+    gen = torch.Generator().manual_seed(bits)
+    q = torch.randint(0, 1 << bits, (r, n), generator=gen, dtype=torch.uint8).to(gpu)
+    scale = (torch.rand(r, n // gsz, generator=gen) * 0.01 + 0.002).half().to(gpu)
+    zero = torch.randint(0, 1 << bits, (r, n // gsz), generator=gen, dtype=torch.uint8).to(gpu)
+    perm_inv = torch.randperm(n, generator=gen).to(torch.int16)
+    meta = {"qweight": q, "scale": scale, "qzero": zero, "qscale": None, "sscale": None, "perm_inv": perm_inv,
+            "group_sizes": torch.full([n // gsz], gsz, dtype=torch.int16), "group_bit_widths": torch.full([n // gsz], bits, dtype=torch.uint8)}
+    w = amd.reconstruct_nn_linear(meta, dtype=torch.float16, device=gpu).weight.data
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    assert layer.bits == bits
+    assert torch.equal(layer(torch.eye(n, dtype=torch.float16, device=gpu)), w.t())
+    back = layer.unpack()
+    assert torch.equal(back["qweight"], q) and torch.equal(back["qzero"], zero) and torch.equal(back["scale"], scale)
+    assert torch.equal(back["perm_inv"].cpu(), perm_inv) and int(back["group_bit_widths"][0]) == bits
+    bad = dict(meta, qweight=q.clone())
+    bad["qweight"][0, 0] = 1 << bits
+    with pytest.raises(ValueError):
+        amd.QuantLinear.from_quant_meta(bad, gpu)

@@ -19,7 +19,7 @@ def run():
     import torch
     lib = ctypes.CDLL(SO)
     dev = torch.device("cuda:0")
-    m, r, c = 8192, 4096, 4096
+    m, r, c = [int(v) for v in os.environ.get("GQ_TRACE_SHAPE", "8192,4096,4096").split(",")]
     q = torch.randint(0, 16, (r, c), device=dev, dtype=torch.uint8)
     pk = torch.empty(r, c // 8, device=dev, dtype=torch.int32)
     assert lib.gq_pack_rows(ctypes.c_void_p(q.data_ptr()), ctypes.c_int64(r), ctypes.c_int64(c), 4, 2,
@@ -36,9 +36,23 @@ def run():
                                ctypes.c_int64(r), ctypes.c_int64(c), 128, None)
         assert rc == 0
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_rep = 20
+    e0.record()
+    for _ in range(n_rep):
+        lib.gq_w4a16_gemm(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(pk.data_ptr()),
+                          ctypes.c_void_p(scale.data_ptr()), ctypes.c_void_p(zero.data_ptr()), ctypes.c_int64(m),
+                          ctypes.c_int64(r), ctypes.c_int64(c), 128, None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n_rep
+    tiles = ((m + 255) // 256) * ((r + 255) // 256)
+    print(f"shape {m}x{r}x{c}: {ms:.4f} ms per launch = {2.0*m*r*c/ms/1e9:.1f} TFLOP/s; {tiles} tiles = {tiles/256:.2f} per CU")
     full = trace.cpu().view(8, 32)
     for w in (0, 4):
         k0, k1, k2, k3, r0, r3 = [int(v) for v in full[w, 13:19]]
+        if w == 0:
+            print(f"  tiles per CU x whole tile time = {tiles/256*(r3-r0)*10/1e6:.4f} ms")
         print(f"wave {w}: prologue {k1-k0} cyc, loop {k2-k1} cyc, epilogue {k3-k2} cyc, whole {k3-k0} cyc = "
               f"{(r3-r0)*10} ns realtime -> {(k3-k0)/((r3-r0)*10):.3f} GHz")
     t = full[:, :10]
