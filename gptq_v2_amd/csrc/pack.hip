@@ -228,10 +228,10 @@ extern "C" int gq_dequantize(const uint8_t *qweight, const void *scale, const ui
 
 extern "C" int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t c, void *x_out, gq_stream_t stream)
 {
-    GQ_REQUIRE(x_in && perm && x_out, "gq_permute_columns: NULL pointer");
     GQ_REQUIRE(m >= 0 && c > 0 && c <= 80 * 1024, "gq_permute_columns: bad shape");
-    GQ_REQUIRE(x_in != x_out, "gq_permute_columns: in-place is not supported");
+    GQ_REQUIRE(perm && ((x_in && x_out) || m == 0), "gq_permute_columns: NULL pointer");   // no rows: no data pointers
     if (m == 0) return GQ_OK;
+    GQ_REQUIRE(x_in != x_out, "gq_permute_columns: in-place is not supported");
     if (c % 8 == 0 && c <= 8 * 2048 && (((uintptr_t)x_in | (uintptr_t)x_out) & 15) == 0) {
         const size_t lds_w = (size_t)(c * 6);
         const int np = (int)gq_cdiv(c / 8, 256);

@@ -763,7 +763,7 @@ namespace {
 int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const void *scale, const uint8_t *qzero, int64_t m,
                  int64_t r, int64_t c, int group_size, int dtype, gq_stream_t stream, const char *who)
 {
-    GQ_REQUIRE(y && x && qweight_packed && scale && qzero, "%s: NULL pointer", who);
+    GQ_REQUIRE(((y && x) || m == 0) && qweight_packed && scale && qzero, "%s: NULL pointer", who);   // no rows: no data pointers
     GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: bad dtype %d", who, dtype);
     GQ_REQUIRE(m >= 0 && r > 0 && c > 0, "%s: bad shape", who);
     GQ_REQUIRE(c % WK == 0, "%s: in_features %lld must be a multiple of %d", who, (long long)c, WK);

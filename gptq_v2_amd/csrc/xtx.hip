@@ -723,7 +723,7 @@ int launch_xtx(float *hess, const unsigned short *x, int64_t n_tokens, int64_t h
 extern "C" int gq_xtx_accumulate(float *hessian, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
                                  int save_lower_only, int compute_lower_only, gq_stream_t stream)
 {
-    GQ_REQUIRE(hessian && x, "gq_xtx_accumulate: NULL pointer");
+    GQ_REQUIRE(hessian && (x || n_tokens == 0), "gq_xtx_accumulate: NULL pointer");   // an empty batch has no data pointer
     GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_xtx_accumulate: dtype %d is neither fp16 (0) nor bf16 (1)", dtype);
     GQ_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden < (1 << 30), "gq_xtx_accumulate: bad shape tokens=%lld hidden=%lld",
                (long long)n_tokens, (long long)hidden);

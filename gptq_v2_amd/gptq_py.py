@@ -149,6 +149,10 @@ def gptq_quant_set(
     k = 0
     for wi, weight in enumerate(weights):
         w = weight if weight.is_contiguous() else weight.contiguous()
+        if w.shape[0] % 4:
+            # the trailing-update GEMMs work on multiples of 4 rows: pad with zero rows (rows are
+            # independent; a zero row quantises to zero error and is cut off again below)
+            w = torch.cat([w, w.new_zeros(4 - w.shape[0] % 4, w.shape[1])], dim=0)
         for b, e in _row_slices(w.shape[0], per_weight):
             with torch.cuda.stream(side[k % len(side)]):
                 res = ops.quantize_layer(w[b:e], perm32, u, gs, gb, sym=quant_symmetric, semantics=sem,
@@ -165,7 +169,7 @@ def gptq_quant_set(
         mine = [j for j in jobs if j[0] == wi]
         n_rows, n_columns = weight.shape
         dtype = weight.dtype
-        cat = (lambda name: mine[0][1][name]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0))
+        cat = (lambda name: mine[0][1][name][:n_rows]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0)[:n_rows])
         sums = torch.stack([j[2] for j in mine]).sum(dim=0).tolist()
         n = float(n_rows * n_columns)
         gptq_error = sums[0] / n

@@ -10,7 +10,10 @@
  *     asynchronous with respect to the host unless stated otherwise;
  *   - return value: 0 on success, a negative GQ_E* code on error; gq_last_error()
  *     returns a thread-local, human-readable description of the last failure;
- *   - dtype codes: GQ_F16 = 0 (IEEE binary16), GQ_BF16 = 1.
+ *   - dtype codes: GQ_F16 = 0 (IEEE binary16), GQ_BF16 = 1;
+ *   - a tensor with zero rows may be passed as NULL (an empty torch tensor has no data
+ *     pointer): gq_xtx_accumulate with n_tokens == 0, gq_permute_columns and the W4A16
+ *     GEMMs with m == 0 return 0 without a launch.
  *
  * Citations "ref:" name the reference interface each entry point replaces
  * (paths are relative to the 4PiR2/gptq-v2 checkout).

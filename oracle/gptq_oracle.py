@@ -301,7 +301,7 @@ def gptq_quant(weight: torch.Tensor, hook: Optional[OracleHessian], group_sizes:
             quant[:, i1:i2] = dequantize(qweight[:, i1:i2], g.scale, g.qzero)
         error = torch.zeros((), dtype=torch.float32)
     elif use_kernel_semantics:  # gptq_py.py:125-157
-        w_t = w.t().contiguous()
+        w_t = w.t().clone(memory_format=torch.contiguous_format)  # a copy even for one row (w stays unmodified)
         quant_t = torch.empty_like(w_t)
         error_t = torch.empty_like(w_t)
         q_t = torch.empty_like(w_t, dtype=torch.int16)

@@ -563,3 +563,36 @@ def test_c_abi_rejects_bad_arguments(amd, gpu):
         amd.ops.xtx_accumulate(h, torch.zeros(64, 128, device=gpu))
     with pytest.raises(ValueError):
         amd.ops.pack_rows(torch.zeros(2, 8, dtype=torch.uint8, device=gpu), 5)
+
+
+def test_empty_and_single_unit_inputs(amd, oracle, gpu):
+    """Zero tokens, zero GEMM rows, one output feature: nothing is launched over an empty range and
+    nothing is read past a one-row tensor."""
+    c = 256
+    hook = amd.HessianHook()
+    x = (torch.randn(2, 96, c, generator=torch.Generator().manual_seed(9)) * (1 + torch.arange(c) / c)).half().to(gpu)
+    hook.add_batch(x)
+    h_before, n_before = hook.hessian.clone(), hook.n_samples
+    hook.add_batch(x[:0])                                   # empty batch: H and the sample count stay
+    assert torch.equal(hook.hessian, h_before) and hook.n_samples == n_before
+    h = torch.zeros(c, c, device=gpu)
+    amd.ops.xtx_accumulate(h, torch.zeros(0, c, dtype=torch.float16, device=gpu))
+    assert not h.any()
+    amd.ops.xtx_accumulate(h, x[0, :1])                     # a single token: the outer product of one row
+    assert torch.equal(h, (x[0, :1].float().t() @ x[0, :1].float()))
+    hook.invert()
+    w = (torch.randn(1, c, generator=torch.Generator().manual_seed(10)) * 0.02).half().to(gpu)   # one output feature
+    gs, gb = torch.tensor([128, 128], dtype=torch.int32), torch.tensor([4, 4], dtype=torch.int32)
+    res = amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False)
+    oh = oracle.OracleHessian()
+    oh.hessian, oh.hessian_inv = hook.hessian.cpu(), hook.hessian_inv.cpu()
+    oh.perm, oh.perm_inv = hook.perm.cpu(), hook.perm_inv.cpu()
+    want = oracle.gptq_quant(w.cpu(), oh, gs, gb, use_kernel_semantics=True)
+    for k in ("qweight", "scale", "qzero", "perm_inv"):
+        assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
+    layer = amd.QuantLinear.from_quant_meta(res["quant_meta"], gpu)
+    y = layer(torch.zeros(0, c, dtype=torch.float16, device=gpu))
+    assert y.shape == (0, 1)
+    y1 = layer(x[0, :3])
+    ref = x[0, :3].float() @ amd.reconstruct_nn_linear(res["quant_meta"], dtype=torch.float16, device=gpu).weight.data.float().t()
+    assert torch.allclose(y1.float(), ref, rtol=2e-3, atol=2e-3)
