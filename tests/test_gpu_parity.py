@@ -596,3 +596,30 @@ def test_empty_and_single_unit_inputs(amd, oracle, gpu):
     y1 = layer(x[0, :3])
     ref = x[0, :3].float() @ amd.reconstruct_nn_linear(res["quant_meta"], dtype=torch.float16, device=gpu).weight.data.float().t()
     assert torch.allclose(y1.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("c", [4, 20, 100, 136, 200, 1000])
+def test_odd_widths_invert_and_quantise(amd, oracle, gpu, c):
+    """Widths that are no multiple of the 128-wide leaves, the 64-column sort pieces or the 16-column
+    sub-blocks: U against the fp64 factor, act-order a valid permutation sorted by the diagonal, and
+    the column loop (one group spanning the width, 4-bit) identical to the CPU restatement."""
+    gen = torch.Generator().manual_seed(c)
+    x = (torch.randn(1, max(2 * c, 64), c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half().to(gpu)
+    hook = amd.HessianHook()
+    hook.add_batch(x)
+    u = hook.invert()
+    assert torch.equal(hook.perm.cpu().sort().values, torch.arange(c))
+    d = hook.hessian.diagonal().cpu()
+    assert (d[:-1] >= d[1:]).all()
+    assert torch.equal(u, u.triu())
+    u64 = oracle.upper_inverse_factor_f64(hook.hessian.cpu())
+    assert (u.cpu().double() - u64).norm() / u64.norm() < 1e-4
+    w = (torch.randn(72, c, generator=gen) * 0.02).half().to(gpu)
+    gs, gb = torch.tensor([c], dtype=torch.int32), torch.tensor([4], dtype=torch.int32)
+    res = amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False)
+    oh = oracle.OracleHessian()
+    oh.hessian, oh.hessian_inv = hook.hessian.cpu(), hook.hessian_inv.cpu()
+    oh.perm, oh.perm_inv = hook.perm.cpu(), hook.perm_inv.cpu()
+    want = oracle.gptq_quant(w.cpu(), oh, gs, gb, use_kernel_semantics=True)
+    for k in ("qweight", "scale", "qzero", "perm_inv"):
+        assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
