@@ -94,3 +94,64 @@ def test_llama70b_down_proj_sizes(amd, gpu):
         d = (amd.reconstruct_nn_linear(meta_, torch.float16, gpu).weight.float() - w.float())[:, hook.perm]
         return float(((d @ h) * d).sum())
     assert hessian_error(meta) < 0.8 * hessian_error(rtn["quant_meta"])
+
+
+def test_llama13b_shapes_with_sample_shards(amd, gpu):
+    """Llama-2-13B widths (C = 5120 and 13824) with the calibration samples split into 8 shards as
+    8 ranks would hold them: the sum of the shard Hessians (what the all-reduce leaves on every
+    rank) equals the single-rank Hessian to fp32 summation accuracy and is exactly symmetric; the
+    inversion of the summed H satisfies U H U^T = I; a 5120-row shard of down_proj quantised
+    against it reconstructs bit for bit from its quant_meta, and row shards of the layer quantised
+    separately equal the layer quantised whole."""
+    from gptq_v2_amd import dist as gd
+    for c, r in ((5120, 1280), (13824, 640)):
+        gen = torch.Generator(device=gpu).manual_seed(c)
+        n_seq, seq = 16, 512
+        x = (torch.randn(n_seq, seq, c, generator=gen, device=gpu) * (1 + 3 * torch.arange(c, device=gpu) / c)).half()
+        whole = amd.HessianHook()
+        whole.add_batch(x)
+        total = torch.zeros(c, c, device=gpu)
+        n_total = 0
+        for rank in range(8):
+            b, e = gd.sample_shard(n_seq, rank, 8)
+            hook = amd.HessianHook()
+            hook.add_batch(x[b:e])
+            total += hook.hessian
+            n_total += hook.n_samples
+            del hook
+        assert n_total == whole.n_samples == n_seq
+        assert torch.equal(total, total.t())
+        scale = float(whole.hessian.abs().max())
+        assert float((total - whole.hessian).abs().max()) <= 2e-6 * scale
+        del x
+        summed = amd.HessianHook()
+        summed.hessian, summed.n_samples = total, n_total
+        u = summed.invert()
+        assert summed.tries == 1 and (u.diagonal() > 0).all()
+        h = summed.hessian
+        worst = 0.0
+        for r0 in range(0, c, 4608):
+            blk = u[r0:r0 + 4608]
+            t2 = torch.matmul(torch.matmul(blk, h), blk.t())
+            worst = max(worst, float((t2 - torch.eye(blk.shape[0], device=gpu)).abs().max()))
+            del t2
+        assert worst < 5e-3, worst
+        w = (torch.randn(r, c, generator=gen, device=gpu) * 0.02).half()
+        gs = torch.full([c // 128], 128, dtype=torch.int32)
+        gb = torch.full([c // 128], 4, dtype=torch.int32)
+        full = amd.gptq_quant(w, summed, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu)
+        parts = []
+        for rank in range(8):
+            b, e = gd.row_shard(r, rank, 8)
+            parts.append(amd.gptq_quant(w[b:e], summed, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False,
+                                        save_device=gpu)["quant_meta"])
+        for k in ("qweight", "scale", "qzero"):
+            assert torch.equal(torch.cat([p[k] for p in parts], dim=0), full["quant_meta"][k]), k
+        lin = amd.reconstruct_nn_linear(full["quant_meta"], dtype=torch.float16, device=gpu)
+        rel = float((lin.weight.float() - w.float()).norm() / w.float().norm())
+        assert 0.02 < rel < 0.35, rel     # 4-bit with few calibration tokens: the error feedback moves weights visibly
+        layer = amd.QuantLinear.from_quant_meta(full["quant_meta"], gpu)
+        back = layer.unpack()
+        assert torch.equal(back["qweight"], full["quant_meta"]["qweight"])
+        del whole, summed, total, u, h, w, lin, layer
+        torch.cuda.empty_cache()
