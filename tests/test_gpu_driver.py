@@ -166,3 +166,75 @@ def test_bf16_model_dense_and_packed_agree(amd, gpu):
     pa = float(driver.evaluate_llama(a, enc, gpu, batch_size=4))
     pb = float(driver.evaluate_llama(b, enc, gpu, batch_size=4))
     assert pa == pytest.approx(pb, rel=0.03) and pa > 1.0
+
+
+def test_dropin_modules_run_the_references_native_loop(amd, gpu):
+    """The modules under gptq_v2_amd/dropin are imported by the names the reference uses (`gptq`,
+    `gptq_triton.accumulate_hessian`, `gptq_py`, `quant`).  The loop the reference's gptq_quant runs on
+    top of its native ops (gptq_py.py:125-157: per group a Quantizer grid from the unmodified weights,
+    then one gptq_quantize_range call) is written out here against those modules and must give what
+    the fused gptq_quant of the same modules returns, bit for bit."""
+    import importlib
+    import os
+    import sys
+    drop = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gptq_v2_amd", "dropin")
+    names = ("gptq", "gptq_triton", "gptq_triton.accumulate_hessian", "gptq_py", "quant")
+    saved = {n: sys.modules.pop(n) for n in names if n in sys.modules}
+    sys.path.insert(0, drop)
+    try:
+        gptq = importlib.import_module("gptq")
+        triton_op = importlib.import_module("gptq_triton.accumulate_hessian").accumulate_hessian
+        gptq_py = importlib.import_module("gptq_py")
+        quant = importlib.import_module("quant")
+        assert os.path.dirname(os.path.abspath(gptq_py.__file__)) == drop
+
+        c, r, t_ = 384, 192, 1024
+        gen = torch.Generator().manual_seed(21)
+        x = (torch.randn(2, t_ // 2, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half().to(gpu)
+        w = (torch.randn(r, c, generator=gen) * 0.02).half().to(gpu)
+
+        # the three ways to the Hessian agree: the hook, the CUTLASS-named op, the Triton-named op
+        hook = gptq_py.HessianHook()
+        hook.add_batch(x)
+        h_full = torch.zeros(c, c, device=gpu)
+        gptq.accumulate_hessian(h_full, x.view(-1, c))
+        h_low = torch.zeros(c, c, device=gpu)
+        triton_op(h_low, x.view(-1, c), False)
+        assert torch.equal(hook.hessian, h_low) and torch.equal(h_low, h_low.t())
+        assert torch.allclose(h_full, h_low, rtol=1e-6, atol=1e-6 * float(h_low.abs().max()))
+        with pytest.raises(NotImplementedError):
+            gptq.accumulate_hessian(h_full, x.view(-1, c).float())
+
+        u = hook.invert()
+        perm = hook.perm
+        gs, gb = torch.tensor([128, 128, 128], dtype=torch.int32), torch.tensor([4, 4, 4], dtype=torch.int32)
+        fused = gptq_py.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False,
+                                   save_device=gpu)["quant_meta"]
+
+        wp = w.float()[:, perm]
+        weight_t = wp.t().contiguous()
+        quant_t, error_t = torch.empty_like(weight_t), torch.empty_like(weight_t)
+        qweight_t = torch.empty_like(weight_t, dtype=torch.int16)
+        quantizers = []
+        for g in range(3):
+            i1, i2 = 128 * g, 128 * (g + 1)
+            qz = quant.Quantizer()
+            qz.find_params(wp[:, i1:i2], 4, sym=False)
+            quantizers.append(qz)
+            gptq.gptq_quantize_range(quant_t, qz.scale.view(-1).contiguous(), qweight_t, qz.qzero.view(-1).contiguous(),
+                                     float(qz.maxq), u, weight_t, error_t, i1, i2)
+        assert torch.equal(qweight_t.t().to(torch.uint8), fused["qweight"])
+        col = quant.collate_quantizers(*quantizers)
+        assert torch.equal(col["scale"].to(torch.float16), fused["scale"])
+        assert torch.equal(col["qzero"].to(torch.uint8), fused["qzero"])
+        lin = quant.reconstruct_nn_linear(fused, dtype=torch.float16, device=gpu)
+        assert torch.equal(lin.weight.data[:, perm], quant_t.t().to(torch.float16))
+        with pytest.raises(RuntimeError):   # H / W shape mismatch, gptq_cpp.cpp:49
+            gptq.gptq_quantize_range(quant_t, quantizers[0].scale.view(-1).contiguous(), qweight_t,
+                                     quantizers[0].qzero.view(-1).contiguous(), 15.0, u[:256, :256].contiguous(), weight_t,
+                                     error_t, 0, 128)
+    finally:
+        sys.path.remove(drop)
+        for n in names:
+            sys.modules.pop(n, None)
+        sys.modules.update(saved)
