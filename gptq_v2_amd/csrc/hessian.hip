@@ -38,8 +38,11 @@ __global__ void scale_kernel(float *__restrict__ h, int64_t c, float s, float *_
     }
 }
 
-// damp = ratio * mean(diag); one workgroup, double accumulation
-__global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float ratio, float *__restrict__ damp_out)
+// damp = ratio * mean(diag); one workgroup, double accumulation.  A diagonal that is not finite
+// (fp16 activations that overflowed put inf or inf * 0 = NaN into X^T X) cannot be repaired by
+// damping: *fatal is raised and the host gives up after the first try.
+__global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float ratio, float *__restrict__ damp_out,
+                            int *__restrict__ fatal)
 {
     __shared__ double part[256];
     double s = 0.0;
@@ -50,11 +53,18 @@ __global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float rat
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *damp_out = ratio * (float)(part[0] / (double)c);
+    if (threadIdx.x == 0) {
+        *damp_out = ratio * (float)(part[0] / (double)c);
+        *fatal = (part[0] - part[0] == 0.0) ? 0 : 1;   // inf - inf and NaN - NaN are NaN
+    }
 }
 
 // Stable descending argsort by counting: rank(i) = #{j : d[j] > d[i] or (d[j] == d[i] and j < i)}.
-// A workgroup ranks 64 elements; its four waves each count one quarter of every 1024-value chunk.
+// The order is total: a NaN counts as smaller than every number and equal to another NaN, so the
+// ranks are a permutation whatever the diagonal holds (with the plain comparisons every NaN would
+// get the same rank, slots of perm would stay unwritten and the gather behind it would read out
+// of bounds).  A workgroup ranks 64 elements; its four waves each count one quarter of every
+// 1024-value chunk.
 __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ perm,
                                                         int32_t *__restrict__ perm_inv)
 {
@@ -63,6 +73,7 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict_
     const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     const float di = i < c ? diag[i] : 0.0f;
+    const bool nan_i = di != di;
     int rank = 0;
     for (int base = 0; base < c; base += 1024) {
         for (int t = threadIdx.x; t < 1024; t += 256) chunk[t] = base + t < c ? diag[base + t] : 0.0f;
@@ -71,7 +82,10 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict_
 #pragma unroll 8
         for (int t = lo; t < lim; ++t) {
             const float dj = chunk[t];
-            rank += (dj > di) || (dj == di && base + t < i);
+            const bool nan_j = dj != dj;
+            const bool above = (dj > di) || (nan_i && !nan_j);
+            const bool same = (dj == di) || (nan_i && nan_j);
+            rank += above || (same && base + t < i);
         }
         __syncthreads();
     }
@@ -118,9 +132,12 @@ __global__ void damp_flip_kernel(float *__restrict__ h, int64_t c, int64_t cp, c
     }
 }
 
-// u[i][j] = linv[c-1-i][c-1-j] on and above the diagonal, 0 below
-__global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64_t cp, float *__restrict__ u)
+// u[i][j] = linv[c-1-i][c-1-j] on and above the diagonal, 0 below; nothing is written when the
+// factorisation before it raised *status (the host then damps again, without a round trip in between)
+__global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64_t cp, float *__restrict__ u,
+                                const int *__restrict__ status)
 {
+    if (*status != 0) return;
     const int64_t total = c * c;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c, col = i - r * c;
@@ -463,7 +480,8 @@ struct InvertWorkspace {
     float *linv;     // cp * cp
     float *diag;     // c
     float *damp;     // 1
-    int *status;     // 1
+    int *status;     // 1: a pivot of the current try was not a positive finite number
+    int *fatal;      // 1: the diagonal is not finite (set once, before the first try)
     int32_t *perm;   // c (used when the caller passes no perm buffer)
     int32_t *perm_inv;
 };
@@ -483,6 +501,7 @@ size_t carve(InvertWorkspace &ws, char *base, int64_t c)
     ws.diag = (float *)take((size_t)c * 4);
     ws.damp = (float *)take(256);
     ws.status = (int *)take(256);
+    ws.fatal = (int *)take(256);
     ws.perm = (int32_t *)take((size_t)c * 4);
     ws.perm_inv = (int32_t *)take((size_t)c * 4);
     return off;
@@ -499,22 +518,23 @@ extern "C" size_t gq_hessian_invert_workspace(int64_t c)
     return carve(ws, nullptr, c);
 }
 
-extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c,
-                                 double n_samples, float damp_ratio, int act_order, int max_try, void *workspace,
-                                 size_t workspace_bytes, int *tries_host, gq_stream_t stream_)
+namespace {
+
+int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c, double n_samples,
+                float damp_ratio, int act_order, int max_try, void *workspace, size_t workspace_bytes, int *tries_host,
+                hipStream_t stream, const char *who)
 {
-    GQ_REQUIRE(hessian && hessian_inv && workspace, "gq_hessian_invert: NULL pointer");
-    GQ_REQUIRE(c > 0 && c <= 32767 * 4, "gq_hessian_invert: bad size %lld", (long long)c);
-    GQ_REQUIRE(n_samples > 0, "gq_hessian_invert: n_samples must be positive");
-    GQ_REQUIRE(!act_order || (perm && perm_inv), "gq_hessian_invert: act_order needs perm and perm_inv buffers");
-    GQ_REQUIRE(max_try >= 1, "gq_hessian_invert: max_try must be >= 1");
+    GQ_REQUIRE(hessian && hessian_inv && workspace, "%s: NULL pointer", who);
+    GQ_REQUIRE(c > 0 && c <= 32767 * 4, "%s: bad size %lld", who, (long long)c);
+    GQ_REQUIRE(n_samples > 0, "%s: n_samples must be positive", who);
+    GQ_REQUIRE(!act_order || (perm && perm_inv), "%s: act_order needs perm and perm_inv buffers", who);
+    GQ_REQUIRE(max_try >= 1, "%s: max_try must be >= 1", who);
     GQ_REQUIRE((((uintptr_t)hessian | (uintptr_t)hessian_inv | (uintptr_t)workspace) & 15) == 0,
-               "gq_hessian_invert: pointers must be 16-byte aligned");
-    hipStream_t stream = (hipStream_t)stream_;
+               "%s: pointers must be 16-byte aligned", who);
     InvertWorkspace ws;
     const size_t need = carve(ws, (char *)workspace, c);
     if (workspace_bytes < need) {
-        gq_set_error("gq_hessian_invert: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+        gq_set_error("%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, need);
         return GQ_EWORKSPACE;
     }
     const int64_t cp = gq_round_up(c, NB);
@@ -522,7 +542,7 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
 
     hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, c, (float)(2.0 / n_samples), ws.diag);
     GQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp);
+    hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp, ws.fatal);
     GQ_LAUNCH_CHECK();
     if (act_order) {
         hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 64)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
@@ -533,6 +553,9 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
     }
     GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
 
+    // One host round trip per try: the factor is flipped into hessian_inv on the device when the try
+    // succeeded (flip_out_kernel looks at the status word itself), and the host reads the verdict
+    // once everything has been enqueued.
     int tries = 0;
     while (tries < max_try) {
         ++tries;
@@ -542,18 +565,33 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
         GQ_LAUNCH_CHECK();
         int rc = cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream);
         if (rc) return rc;
-        int status = 0;
-        GQ_HIP(hipMemcpyAsync(&status, ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv, ws.status);
+        GQ_LAUNCH_CHECK();
+        int verdict[2] = {0, 0};   // status and fatal are 256 bytes apart
+        GQ_HIP(hipMemcpyAsync(&verdict[0], ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
+        GQ_HIP(hipMemcpyAsync(&verdict[1], ws.fatal, sizeof(int), hipMemcpyDeviceToHost, stream));
         GQ_HIP(hipStreamSynchronize(stream));
-        if (status == 0) {
-            hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv);
-            GQ_LAUNCH_CHECK();
-            GQ_HIP(hipStreamSynchronize(stream));
+        if (verdict[1]) {
+            if (tries_host) *tries_host = tries;
+            gq_set_error("%s: the Hessian's diagonal is not finite (overflowed activations?)", who);
+            return GQ_ENOTPD;
+        }
+        if (verdict[0] == 0) {
             if (tries_host) *tries_host = tries;
             return GQ_OK;
         }
     }
     if (tries_host) *tries_host = tries;
-    gq_set_error("gq_hessian_invert: not positive definite after %d dampings", tries);
+    gq_set_error("%s: not positive definite after %d dampings", who, tries);
     return GQ_ENOTPD;
+}
+
+}  // namespace
+
+extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c,
+                                 double n_samples, float damp_ratio, int act_order, int max_try, void *workspace,
+                                 size_t workspace_bytes, int *tries_host, gq_stream_t stream_)
+{
+    return invert_impl(hessian, hessian_inv, perm, perm_inv, c, n_samples, damp_ratio, act_order, max_try, workspace,
+                       workspace_bytes, tries_host, (hipStream_t)stream_, "gq_hessian_invert");
 }

@@ -340,6 +340,36 @@ extern "C" int gq_debug_qb_trace(unsigned long long *buf)
 }
 #endif
 
+// ---- one column, one thread per output feature ------------------------------------------------
+// The reference's own decomposition (gptq_cpp_kernel.cu:21-137: quantise column `col`, then the
+// rank-1 update of everything behind it), for the columns of a range that the blocked kernel cannot
+// take: a head or tail that is not aligned to 4 columns, or shapes whose rows of U are not 16-byte
+// aligned.  Every later column receives the same fused multiply-add it receives from the blocked
+// kernel and the trailing GEMM, so mixing the two forms changes no bit.
+__global__ __launch_bounds__(256) void quant_col_kernel(float *__restrict__ wt, float *__restrict__ quant_t,
+                                                        float *__restrict__ error_t, int16_t *__restrict__ q_out,
+                                                        const float *__restrict__ u, const float *__restrict__ scale,
+                                                        const float *__restrict__ zero, int64_t c_total, int64_t r_total,
+                                                        int64_t col, float maxq)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= r_total) return;
+    const float s = scale[r], z = zero[r];
+    const float x = wt[col * r_total + r];
+    const float qf = clampf(rintf(x / s) + z, 0.0f, maxq);
+    const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
+    _Float16 hd = hx - hz;
+    hd = hd * hs;
+    const float dq = (float)hd;
+    const float *__restrict__ urow = u + col * c_total;
+    const float err = (x - dq) / urow[col];
+    quant_t[col * r_total + r] = dq;
+    error_t[col * r_total + r] = err;
+    if (q_out) q_out[col * r_total + r] = (int16_t)(uint16_t)qf;
+    const float nerr = -err;
+    for (int64_t c2 = col + 1; c2 < c_total; ++c2) wt[c2 * r_total + r] = fmaf(nerr, urow[c2], wt[c2 * r_total + r]);
+}
+
 // ---- grid for all groups from the unmodified weights (static groups) ------------------------
 __global__ void find_params_kernel(const float *__restrict__ wt, int64_t r_total, int64_t col0, int64_t ncols,
                                    float maxq, int sym, float *__restrict__ scale, float *__restrict__ zero)
@@ -845,12 +875,27 @@ extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_
     GQ_REQUIRE(c > 0 && r > 0 && 0 <= a && a <= b && b <= c, "gq_quantize_range: bad range [%lld, %lld) of %lld",
                (long long)a, (long long)b, (long long)c);
     GQ_REQUIRE(r <= (1 << 22) && c <= (1 << 22), "gq_quantize_range: at most 2^22 rows and columns");
-    GQ_REQUIRE(r % 4 == 0 && c % 4 == 0 && (b - a) % 4 == 0 && a % 4 == 0,
-               "gq_quantize_range: out_features, in_features and the range must be multiples of 4");
     hipStream_t stream = (hipStream_t)stream_;
+    auto single = [&](int64_t col) -> int {
+        hipLaunchKernelGGL(quant_col_kernel, dim3((unsigned)gq_cdiv(r, 256)), dim3(256), 0, stream, weights, quant, error, out_q,
+                           hessian_inv, scale, qzero, c, r, col, maxq);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    };
+    // The blocked kernel and the trailing GEMM read U and the weights in 16-byte pieces: they take
+    // the part of the range that starts and ends on a multiple of 4 columns when both dimensions
+    // are multiples of 4; any other column goes through the one-column kernel (the reference takes
+    // any range, gptq_cpp.cpp:51).
+    const bool aligned = r % 4 == 0 && c % 4 == 0;
+    const int64_t a4 = aligned ? std::min(b, gq_round_up(a, 4)) : b;
+    const int64_t b4 = aligned ? std::max(a4, b - b % 4) : b;
+    for (int64_t col = a; col < a4; ++col) {
+        int rc = single(col);
+        if (rc) return rc;
+    }
     // any range is cut into register-sized blocks; the result does not depend on the cut
-    for (int64_t s0 = a, s1; s0 < b; s0 = s1) {
-        s1 = s0 + block_size_for(b - s0);
+    for (int64_t s0 = a4, s1; s0 < b4; s0 = s1) {
+        s1 = s0 + block_size_for(b4 - s0);
         QuantBlockArgs p{};
         p.wt = weights; p.quant_t = quant; p.error_t = error; p.q_out = out_q; p.u = hessian_inv;
         p.scale = const_cast<float *>(scale); p.zero = const_cast<float *>(qzero);
@@ -860,6 +905,10 @@ extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_
         if (rc) return rc;
         // the reference updates rows [c+1, b) in its loop and rows [b, C) afterwards; both are this chain
         if ((rc = trailing_update(hessian_inv, weights, error, c, r, s0, s1, s1, c, stream))) return rc;
+    }
+    for (int64_t col = b4; col < b; ++col) {
+        int rc = single(col);
+        if (rc) return rc;
     }
     return GQ_OK;
 }

@@ -346,3 +346,28 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
     if (blocks128 < 256) return launch_sgemm<64>(args, stream);
     return launch_sgemm<128>(args, stream);
 }
+
+// H += X^T X for fp32 activations: the reference's fp32 addmm (gptq_py.py:31-33).  Full product;
+// H[i][j] and H[j][i] are the same k-ascending chain of commutative fused multiply-adds, so H comes
+// out exactly symmetric.
+extern "C" int gq_xtx_accumulate_f32(float *hessian, const float *x, int64_t n_tokens, int64_t hidden, gq_stream_t stream)
+{
+    GQ_REQUIRE(hessian && (x || n_tokens == 0), "gq_xtx_accumulate_f32: NULL pointer");
+    GQ_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden < (1 << 30) && n_tokens < ((int64_t)1 << 31),
+               "gq_xtx_accumulate_f32: bad shape tokens=%lld hidden=%lld", (long long)n_tokens, (long long)hidden);
+    GQ_REQUIRE(n_tokens % 4 == 0 && hidden % 4 == 0,
+               "gq_xtx_accumulate_f32: tokens (%lld) and hidden (%lld) must be multiples of 4 (pad with zero rows)",
+               (long long)n_tokens, (long long)hidden);
+    if (n_tokens == 0) return GQ_OK;
+    GqSgemmArgs g{};
+    g.a = x; g.b = x; g.c = hessian;
+    g.lda = g.ldb = g.ldc = hidden;
+    g.m = g.n = (int)hidden;
+    g.k = (int)n_tokens;
+    g.layout = GQ_A_KM | GQ_B_KN;
+    g.trim = GQ_TRIM_NONE;
+    g.negate = 0;
+    g.accumulate = 1;
+    g.lower_only = 0;
+    return gq_sgemm(g, (hipStream_t)stream);
+}

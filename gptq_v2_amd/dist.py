@@ -83,3 +83,42 @@ def allgather_rows(local: Dict[str, torch.Tensor], n_rows: int, multiple: int = 
                 gathered[r].copy_(host[r])
         out[name] = torch.cat([gathered[r, : e - b] for r, (b, e) in enumerate(bounds)], dim=0)
     return out
+
+
+def gather_quant_result(local, layer_fields: dict, n_rows: int, n_columns: int, dtype: torch.dtype, device,
+                        multiple: int = 64) -> dict:
+    """One Linear's ``{'quant_meta', 'metrics'}`` for all rows from every rank's row shard.
+    ``local``: this rank's result of ``gptq_quant`` on its ``row_shard`` rows, or None if that shard is
+    empty (a Linear with fewer 64-row units than ranks).  Per-row tensors are concatenated in rank
+    order.  ``layer_fields``: the entries of ``quant_meta`` that do not depend on the rows
+    (``perm_inv``, ``group_sizes``, ``group_bit_widths``, ...), which every rank can state from the
+    Hessian it holds; used where ``local`` is None.  The four metrics are means over elements and
+    are combined with the shards' row counts as weights."""
+    rank, ws = world()
+    b, e = row_shard(n_rows, rank, ws, multiple)
+    n_groups = len(layer_fields["group_sizes"])
+    if local is None:
+        if e != b:
+            raise ValueError("a rank with rows must pass its result")
+        parts = {"qweight": torch.empty(0, n_columns, dtype=torch.uint8, device=device),
+                 "scale": torch.empty(0, n_groups, dtype=dtype, device=device),
+                 "qzero": torch.empty(0, n_groups, dtype=torch.uint8, device=device)}
+        sums = torch.zeros(4, dtype=torch.float64)
+        fields = layer_fields
+    else:
+        meta = local["quant_meta"]
+        parts = {k: meta[k].to(device) for k in ("qweight", "scale", "qzero")}
+        m = local["metrics"]
+        sums = torch.tensor([m["gptq_error"], m["gptq_norm"], m["l2.0_error"], m["l2.0_norm"]], dtype=torch.float64) * (e - b)
+        fields = {k: v for k, v in meta.items() if k not in parts}
+    full = allgather_rows(parts, n_rows, multiple)
+    if ws > 1:
+        if dist.get_backend() == "nccl":
+            sums = sums.to(device)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    sums = (sums.cpu() / n_rows).tolist()
+    out_meta = dict(fields)
+    out_meta.update(full)
+    metrics = {"gptq_error": sums[0], "gptq_norm": sums[1], "l2.0_error": sums[2],
+               "l2.0_norm": torch.tensor(sums[3], dtype=torch.float64).to(dtype).item()}
+    return {"quant_meta": out_meta, "metrics": metrics}

@@ -23,6 +23,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
+from . import dist as gd
 from .gptq_py import HessianHook, gptq_quant_set
 from .quant import QuantLinear, reconstruct_weight
 
@@ -125,8 +126,17 @@ def quantize_llama(
         quant_mse: bool = False,
         scale_bit_width: Optional[int] = None,
         staged: Optional[bool] = None,
+        offload: bool = False,
 ) -> Dict[str, Dict[str, dict]]:
     """Quantise every decoder block of ``model`` in place (llama.py:64-204).
+
+    Under an initialised ``torch.distributed`` process group (one process per GPU) the work is
+    shared: every rank walks the blocks with ITS shard of the calibration sequences
+    (``dist.sample_shard``), the Hessian of each input-sharing set is summed over ranks, every rank
+    inverts it (bit-identical inputs, deterministic kernels: identical ``perm`` and ``U``), the rows
+    of each Linear are split over ranks for the column loop and the integer levels, scales and zero
+    points are gathered, so every rank ends with the same quantised block and the same results.
+    The reference is single-GPU (parse_args.py:53-55).
 
     After the call each Linear holds the dense reconstructed weight (what the reference leaves in
     the model), or is replaced by a packed ``QuantLinear`` when ``pack`` is set.  ``on_set(block
@@ -134,7 +144,21 @@ def quantize_llama(
     before its weights change (for inspection and tests).  ``symmetric``, ``quant_mse`` and
     ``scale_bit_width`` are the grid options the reference hard-codes to off (llama.py:146-163).
     ``staged``: walk Llama-layout blocks in stages from cached activations (None: when the block
-    has that layout; False: always re-run the block up to each hooked Linear)."""
+    has that layout; False: always re-run the block up to each hooked Linear; True is only valid
+    with the default ``sets``).  ``offload``: move each finished block back to the CPU, as the
+    reference does (llama.py:194-196); without it the whole quantised model stays on ``device``
+    (about 2 bytes per weight: 13 GB for Llama-2-7B, 138 GB for 70B, inside one MI355X's 288 GB)."""
+    if staged and [list(s_) for s_ in sets] != LLAMA_SETS:
+        raise ValueError("staged=True walks the Llama block layout and needs the default `sets`")
+    rank, world = gd.world()
+    if world > 1:
+        if scale_bit_width is not None and int(scale_bit_width) > 0:
+            raise NotImplementedError("EXL2 scale quantisation takes a maximum over all rows of a group: not offered "
+                                      "together with row sharding over ranks")
+        sb, se = gd.sample_shard(len(encodings), rank, world)
+        if se == sb:
+            raise ValueError(f"{len(encodings)} calibration sequences cannot be split over {world} ranks")
+        encodings = encodings[sb:se]
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
     use_cache, model.config.use_cache = model.config.use_cache, False
@@ -148,6 +172,8 @@ def quantize_llama(
     def quantise_set(gi, block, names, hook):
         """invert + quantise + put the results into the block; the Hessian is complete"""
         mods = [_submodule(block, nm) for nm in names]
+        if world > 1:
+            hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
         hook.invert(damp_ratio=damp_ratio, act_order=act_order)
         weights = [m.weight.data for m in mods]
         c = weights[0].shape[1]
@@ -157,9 +183,25 @@ def quantize_llama(
         gb = torch.full([c // group_size], bits, dtype=torch.int32)
         if on_set is not None:
             on_set(gi, list(names), hook, weights)
-        outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
-                              gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
-                              save_device=device)
+        if world > 1:
+            shards = [gd.row_shard(w.shape[0], rank, world) for w in weights]
+            mine = [(i, w[b:e]) for i, (w, (b, e)) in enumerate(zip(weights, shards)) if e > b]   # a short Linear may leave a rank without rows
+            part = gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
+                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
+                                  save_device=device)
+            by_index = {i: res for (i, _), res in zip(mine, part)}
+            c_ = weights[0].shape[1]
+            fields = {"qscale": None, "sscale": None, "scale_bit_width": None if sbw is None else sbw.to(torch.uint8).to(device),
+                      "perm_inv": (hook.perm_inv.to(torch.int16) if hook.perm_inv is not None
+                                   else torch.arange(c_, dtype=torch.int16, device=device)),
+                      "group_sizes": gs.to(dtype=torch.int16, device=device),
+                      "group_bit_widths": gb.to(dtype=torch.uint8, device=device)}
+            outs = [gd.gather_quant_result(by_index.get(i), fields, w.shape[0], c_, w.dtype, device)
+                    for i, w in enumerate(weights)]
+        else:
+            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
+                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
+                                  save_device=device)
         for name, mod, res in zip(names, mods, outs):
             canonical = f"model.layers.{gi}.{name}"
             meta = res["quant_meta"]
@@ -241,6 +283,8 @@ def quantize_llama(
             for b, e in batches:
                 nxt[b:e] = _first(block(inps[b:e], **inp_kwargs))
         inps = nxt
+        if offload:
+            block.to("cpu")
         results["seconds_per_block"].append(time.time() - t0)
 
     model.config.use_cache = use_cache
@@ -248,9 +292,12 @@ def quantize_llama(
 
 
 @torch.no_grad()
-def evaluate_llama(model: nn.Module, encodings: torch.Tensor, device: torch.device, batch_size: int = 1) -> torch.Tensor:
+def evaluate_llama(model: nn.Module, encodings: torch.Tensor, device: torch.device, batch_size: int = 1,
+                   loss_in_fp32: bool = False) -> torch.Tensor:
     """Perplexity over ``encodings`` (B, N), block by block as the reference evaluates
-    (llama.py:207-247): mean over sequences of the per-batch token cross-entropy, exponentiated."""
+    (llama.py:207-247): mean over sequences of the per-batch token cross-entropy, exponentiated.
+    The cross-entropy is taken on the logits in the model's own dtype, as the reference does
+    (llama.py:241); ``loss_in_fp32`` casts them to fp32 first."""
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
     use_cache, model.config.use_cache = model.config.use_cache, False
@@ -270,7 +317,8 @@ def evaluate_llama(model: nn.Module, encodings: torch.Tensor, device: torch.devi
     for bi in range(0, len(inps), batch_size):
         logits = model.lm_head(inps[bi:bi + batch_size])
         labels = encodings[bi:bi + batch_size, 1:].to(device)
-        nll = loss(logits[:, :-1, :].flatten(end_dim=-2).float(), labels.flatten())
+        flat = logits[:, :-1, :].flatten(end_dim=-2)
+        nll = loss(flat.float() if loss_in_fp32 else flat, labels.flatten())
         nlls.extend([nll] * len(logits))
     model.config.use_cache = use_cache
     return torch.stack(nlls).to(torch.float32).mean().exp()

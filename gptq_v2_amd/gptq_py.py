@@ -31,10 +31,12 @@ class HessianHook:
 
     @torch.no_grad()
     def add_batch(self, inp: torch.Tensor, use_kernel: bool = True) -> None:
-        """inp (..., N, D) fp16/bf16.  ``n_samples`` counts sequences, a 2-D input is one sequence
-        (gptq_py.py:25-27).  ``use_kernel`` is accepted for signature compatibility: both of the
-        reference's branches compute H += X^T X with fp32 accumulation, which is what the HIP
-        kernel does; there is no second implementation to switch to."""
+        """inp (..., N, D).  ``n_samples`` counts sequences, a 2-D input is one sequence
+        (gptq_py.py:25-27).  ``use_kernel=True``: fp16 / bf16 activations on the 16-bit matrix core
+        (the reference's native and Triton ops take no other type, package/gptq/__init__.py:12-13).
+        ``use_kernel=False``: the input is cast to fp32 first, whatever its type, and accumulated with
+        fp32 products on the fp32 matrix core (the reference's torch.addmm branch, gptq_py.py:31-33);
+        for 16-bit inputs both give the same H up to the order of the fp32 additions."""
         assert self.hessian_inv is None
         assert not hasattr(inp, "fake_mode")
         if inp.dim() <= 2:
@@ -44,6 +46,9 @@ class HessianHook:
         if self.hessian is None:
             self.hessian = torch.zeros(d, d, dtype=torch.float32, device=inp.device)
         x = inp.flatten(end_dim=-2)
+        if not use_kernel:
+            ops.xtx_accumulate_f32(self.hessian, x.to(dtype=torch.float32).contiguous())
+            return
         if not x.is_contiguous():
             x = x.contiguous()
         ops.xtx_accumulate(self.hessian, x, save_lower_only=False, compute_lower_only=True)
@@ -252,7 +257,14 @@ def gptq_quant(
 
 
 class GPTQ:
-    """``add_batch`` / ``fasterquant`` names over HessianHook + gptq_quant for one Linear."""
+    """``add_batch`` / ``fasterquant`` names over HessianHook + gptq_quant for one Linear.
+
+    ``blocksize`` is the lazy-batch block of the column loop.  With ``static_groups`` (the
+    reference's native loop, gptq_py.py:125-157) every group's grid comes from the unmodified
+    weights and each weight receives the same chain of updates however the columns are cut, so the
+    result does not depend on it; without (the PyTorch loop, gptq_py.py:158-193) the grids are taken
+    from the weights as they are at the start of the block a group begins in, and ``blocksize`` is
+    passed on as ``gptq_block_sizes``."""
 
     def __init__(self, layer: torch.nn.Linear) -> None:
         self.layer = layer
@@ -269,9 +281,12 @@ class GPTQ:
         gsz = c if groupsize in (-1, None) else groupsize
         if c % gsz:
             raise ValueError("in_features must be a multiple of the group size")
+        if blocksize is None or blocksize <= 0 or blocksize % 4:
+            raise ValueError("blocksize must be a positive multiple of 4")
         group_sizes = torch.full([c // gsz], gsz, dtype=torch.int32)
         group_bits = torch.full([c // gsz], bits, dtype=torch.int32)
+        blocks = [blocksize] * (c // blocksize) + ([c % blocksize] if c % blocksize else [])
         self.hook.invert(damp_ratio=percdamp, act_order=actorder)
         return gptq_quant(w, self.hook, group_sizes, group_bits, gptq_use_kernel=static_groups,
-                          gptq_block_sizes=group_sizes, quant_symmetric=sym, quant_mse=False,
+                          gptq_block_sizes=torch.tensor(blocks, dtype=torch.int32), quant_symmetric=sym, quant_mse=False,
                           save_device=save_device if save_device is not None else w.device)

@@ -68,6 +68,26 @@ def xtx_accumulate(hessian: torch.Tensor, x: torch.Tensor, save_lower_only: bool
     _lib.check(rc, "gq_xtx_accumulate")
 
 
+def xtx_accumulate_f32(hessian: torch.Tensor, x: torch.Tensor) -> None:
+    """hessian (C, C) fp32 += x^T x for x (N, C) fp32 (the reference's add_batch(use_kernel=False)
+    arithmetic, gptq_py.py:31-33).  N is padded to a multiple of 4 with zero rows."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(x, "x", torch.float32, 2)
+    n, c = x.shape
+    if hessian.shape != (c, c):
+        raise ValueError(f"hessian is {tuple(hessian.shape)}, x has {c} columns")
+    if x.device != hessian.device:
+        raise ValueError("hessian and x are on different devices")
+    if c % 4:
+        raise NotImplementedError("fp32 activations: the hidden size must be a multiple of 4")
+    if n % 4:
+        x = torch.cat([x, x.new_zeros(4 - n % 4, c)], dim=0)
+        n = x.shape[0]
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_xtx_accumulate_f32(_p(hessian), _p(x), n, c, _stream(x))
+    _lib.check(rc, "gq_xtx_accumulate_f32")
+
+
 def hessian_invert(hessian: torch.Tensor, n_samples: float, damp_ratio: float = 1e-2, act_order: bool = True,
                    max_try: int = 100) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor], int]:
     """In place on ``hessian`` (scaled, permuted, damped as the reference leaves it).

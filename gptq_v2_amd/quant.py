@@ -189,12 +189,19 @@ def reconstruct_weight(quant_meta: dict, dtype: torch.dtype, device) -> torch.Te
     return ops.dequantize(qweight, scale, qzero, perm_inv, gs)
 
 
-def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.device = None) -> nn.Linear:
-    """Dense ``nn.Linear`` (no bias) from a ``quant_meta`` dict (quant.py:262-279).  The
-    dequantisation runs on the GPU, so ``device`` must be a GPU (the reference defaults to CPU)."""
-    if device is None:
-        device = quant_meta["qweight"].device
-    weight = reconstruct_weight(quant_meta, dtype, device)
+def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.device = torch.device("cpu")) -> nn.Linear:
+    """Dense ``nn.Linear`` (no bias) from a ``quant_meta`` dict (quant.py:262-279), placed on
+    ``device`` (default CPU, as in the reference).  The dequantisation itself always runs on a GPU:
+    on ``device`` when that is one, else on the GPU that holds ``qweight`` or the current GPU, and
+    the finished weight is moved."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        compute = device
+    elif quant_meta["qweight"].device.type == "cuda":
+        compute = quant_meta["qweight"].device
+    else:
+        compute = torch.device("cuda", torch.cuda.current_device())
+    weight = reconstruct_weight(quant_meta, dtype, compute).to(device)
     with torch.device("meta"):
         lin = nn.Linear(weight.shape[1], weight.shape[0], bias=False, dtype=dtype)
     lin.weight = nn.Parameter(weight, requires_grad=False)

@@ -58,6 +58,13 @@ int gq_version(void);
 int gq_xtx_accumulate(float *hessian, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
                       int save_lower_only, int compute_lower_only, gq_stream_t stream);
 
+/* The same accumulation for fp32 activations X[n_tokens][hidden]: full product on the fp32 matrix
+ * core, every element one k-ascending chain of fused multiply-adds (exactly symmetric result).
+ * n_tokens and hidden must be multiples of 4 (zero rows may be appended to X).
+ * ref: gptq_py.py:31-33 (add_batch(use_kernel=False): torch.addmm on the fp32 cast of the input). */
+int gq_xtx_accumulate_f32(float *hessian, const float *x, int64_t n_tokens, int64_t hidden,
+                          gq_stream_t stream);
+
 /* Bytes of workspace gq_hessian_invert needs for a C x C Hessian. */
 size_t gq_hessian_invert_workspace(int64_t c);
 
@@ -70,8 +77,10 @@ size_t gq_hessian_invert_workspace(int64_t c);
  * *tries_host = number of dampings applied.  U is obtained as the inverse of the factor of the
  * index-reversed matrix (J H J = L L^T  =>  U = J L^-1 J), mathematically the factor the
  * reference gets from cholesky -> cholesky_inverse -> cholesky(upper), at half the flops.
- * A try fails when a pivot is <= 0 or not finite (the reference tests the result for NaN).
- * Synchronous: returns after the stream has drained.
+ * A try fails when a pivot is <= 0 or not finite (the reference tests the result for NaN); a
+ * diagonal that is not finite to begin with fails after the first try with GQ_ENOTPD (damping
+ * cannot repair it; the reference runs out its 100 tries and asserts).
+ * Synchronous: returns after the stream has drained (one host round trip per try).
  * ref: gptq_py.py:38-66. */
 int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv,
                       int64_t c, double n_samples, float damp_ratio, int act_order, int max_try,
@@ -89,6 +98,8 @@ int gq_find_params(const float *weights_t, int64_t c, int64_t r, int64_t col0, i
  * int16 or NULL, scale/qzero are [R] fp32, hessian_inv is U [C][C].
  * Per column c: x = clamp(rint(w/s)+z, 0, maxq); q = half(half(x)-half(z))*half(s);
  * e = (w-q)/U[c][c]; w[c'] = fma(-e, U[c][c'], w[c']) for every c' > c (ascending c).
+ * Any 0 <= a <= b <= C is accepted, as in the reference; columns outside the largest sub-range
+ * aligned to 4 (all of them when R or C is not a multiple of 4) take a one-column-per-launch path.
  * ref: package/gptq/__init__.py:16-28, gptq_cpp.cpp:33-84, gptq_cpp_kernel.cu:21-158. */
 int gq_quantize_range(float *quant, const float *scale, int16_t *out_q, const float *qzero, float maxq,
                       const float *hessian_inv, float *weights, float *error, int64_t c, int64_t r,

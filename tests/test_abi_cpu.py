@@ -22,9 +22,10 @@ def _declared():
 def test_header_declares_what_we_think():
     names = _declared()
     for must in ("gq_xtx_accumulate", "gq_hessian_invert", "gq_quantize_range", "gq_quantize_layer",
-                 "gq_quantize_layer_ex", "gq_quantize_rtn", "gq_dequantize", "gq_pack_rows", "gq_w4a16_gemm", "gq_w4a16_gemm_dt"):
+                 "gq_quantize_layer_ex", "gq_quantize_rtn", "gq_dequantize", "gq_pack_rows", "gq_w4a16_gemm", "gq_w4a16_gemm_dt",
+                 "gq_xtx_accumulate_f32"):
         assert must in names
-    assert len(names) == 18
+    assert len(names) >= 19
 
 
 def test_library_exports_every_declared_symbol():
@@ -62,6 +63,7 @@ def test_bad_arguments_are_rejected_before_the_device_is_touched():
     assert lib.gq_xtx_accumulate(one, one, 0, 16, 16, 1, 0, None) == -1          # save_lower_only without compute_lower_only
     assert lib.gq_w4a16_gemm(one, one, one, one, one, 8, 64, 100, 128, None) == -1   # in_features not a multiple of 64
     assert lib.gq_pack_rows(one, 4, 64, 5, 0, one, None) == -1                    # 5-bit values
+    assert lib.gq_xtx_accumulate_f32(one, one, 6, 16, None) == -1                 # token count not a multiple of 4
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(_lib.GqError):

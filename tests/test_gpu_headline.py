@@ -1,0 +1,130 @@
+"""The odd width of the headline configuration: Llama-2-7B's down_proj has 11008 input features,
+which is 43 tiles of 256 (an odd tile grid for the Hessian kernel), 86 leaves of 128 (uneven
+splits at every level of the inversion's recursion), 86 groups of 128 in the column loop and 172
+k-steps of the packed GEMM.  Every stage is checked at that width: against fp64 where the
+arithmetic is fp32 sums, bit for bit against the CPU oracle where it is defined to the bit."""
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+C = 11008
+
+
+def _activations(gpu, n_seq, seq, seed):
+    gen = torch.Generator(device=gpu).manual_seed(seed)
+    return (torch.randn(n_seq, seq, C, generator=gen, device=gpu) * (1 + 3 * torch.arange(C, device=gpu) / C)).half()
+
+
+@pytest.fixture(scope="module")
+def down_proj_hook(amd, gpu):
+    """Hessian of 8192 tokens over two add_batch calls, kept before and after invert()."""
+    hook = amd.HessianHook()
+    xs = [_activations(gpu, 2, 2048, 100 + i) for i in range(2)]
+    for x in xs:
+        hook.add_batch(x)
+    raw = hook.hessian.clone()
+    hook.invert(damp_ratio=1e-2, act_order=True)
+    return hook, raw, xs
+
+
+def test_down_proj_hessian(down_proj_hook, gpu):
+    """Exactly symmetric; sampled rows against the fp64 product of the same fp16 activations."""
+    hook, raw, xs = down_proj_hook
+    assert hook.n_samples == 4
+    assert torch.equal(raw, raw.t())
+    rows = torch.tensor([0, 1, 255, 256, 257, 4095, 4096, 5503, 5504, 10751, 10752, 11007], device=gpu)
+    want = torch.zeros(len(rows), C, dtype=torch.float64, device=gpu)
+    for x in xs:
+        x2 = x.reshape(-1, C).double()
+        want += x2[:, rows].t() @ x2
+    got = raw[rows].double()
+    # fp32 accumulation over 8192 products per element: relative to the row's largest entry
+    assert ((got - want).abs().max(dim=1).values <= 2e-6 * want.abs().max(dim=1).values).all()
+
+
+def test_down_proj_invert(down_proj_hook, oracle, gpu):
+    """perm is the stable descending order of the scaled diagonal; U is upper triangular with a
+    positive diagonal, within 1e-4 (relative Frobenius) of the fp64 factor of the Hessian the call
+    leaves behind, and U H U^T = I."""
+    hook, raw, _ = down_proj_hook
+    assert hook.tries == 1
+    diag = raw.diagonal() * (2.0 / hook.n_samples)
+    assert torch.equal(hook.perm, torch.argsort(diag, descending=True, stable=True))
+    u, h = hook.hessian_inv, hook.hessian
+    assert (u.diagonal() > 0).all() and torch.isfinite(u).all()
+    assert torch.count_nonzero(torch.tril(u, -1)) == 0
+    u64 = oracle.upper_inverse_factor_f64(h.cpu())
+    assert (u.cpu().double() - u64).norm() / u64.norm() < 1e-4
+    worst = 0.0
+    for r0 in range(0, C, 2752):
+        blk = u[r0:r0 + 2752]
+        t2 = torch.matmul(torch.matmul(blk, h), blk.t())
+        worst = max(worst, float((t2 - torch.eye(blk.shape[0], device=gpu)).abs().max()))
+    assert worst < 5e-3, worst
+
+
+def test_down_proj_column_loop_bit_exact(down_proj_hook, amd, oracle, gpu):
+    """A 256-row shard of the 4096 x 11008 layer through the native-loop semantics (86 groups, 22
+    super-blocks of the two-level trailing update) with the GPU's U and perm handed to the CPU
+    oracle: every level, scale, zero point identical, metrics to summation accuracy.  The oracle
+    walks the rows in four independent 64-row pieces (rows do not interact)."""
+    hook, _, _ = down_proj_hook
+    r = 256
+    gen = torch.Generator(device=gpu).manual_seed(7)
+    w = (torch.randn(r, C, generator=gen, device=gpu) * 0.02).half()
+    gs = torch.full([C // 128], 128, dtype=torch.int32)
+    gb = torch.full([C // 128], 4, dtype=torch.int32)
+    res = amd.gptq_quant(w, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False)
+    oh = oracle.OracleHessian()
+    oh.hessian, oh.hessian_inv = hook.hessian.cpu(), hook.hessian_inv.cpu()
+    oh.perm, oh.perm_inv = hook.perm.cpu(), hook.perm_inv.cpu()
+    wc = w.cpu()
+
+    def piece(i):
+        return oracle.gptq_quant(wc[i:i + 64], oh, gs, gb, use_kernel_semantics=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        wants = list(ex.map(piece, range(0, r, 64)))
+    for k in ("qweight", "scale", "qzero"):
+        assert torch.equal(res["quant_meta"][k], torch.cat([w_["quant_meta"][k] for w_ in wants], dim=0)), k
+    assert torch.equal(res["quant_meta"]["perm_inv"], wants[0]["quant_meta"]["perm_inv"])
+    for k in ("gptq_error", "gptq_norm", "l2.0_error"):
+        mean = sum(w_["metrics"][k] for w_ in wants) / len(wants)
+        assert res["metrics"][k] == pytest.approx(mean, rel=1e-4), k
+    # and the packed layer gives the integers back
+    layer = amd.QuantLinear.from_quant_meta(res["quant_meta"], gpu)
+    assert torch.equal(layer.unpack()["qweight"].cpu(), res["quant_meta"]["qweight"])
+
+
+@pytest.mark.parametrize("m", [2048, 16384])
+def test_down_proj_packed_forward(amd, gpu, m):
+    """QuantLinear.forward of a 4096 x 11008 layer (172 k-steps) with act-order at the two serving
+    batch sizes (seq 2048 x batch 1 and 8): sampled rows and columns against the fp64 contraction of
+    the dequantised weight."""
+    gen = torch.Generator(device=gpu).manual_seed(m)
+    r, gsz = 4096, 128
+    q = torch.randint(0, 16, (r, C), generator=gen, device=gpu, dtype=torch.uint8)
+    scale = (torch.rand(r, C // gsz, generator=gen, device=gpu) * 0.01 + 0.002).half()
+    zero = torch.randint(0, 16, (r, C // gsz), generator=gen, device=gpu, dtype=torch.uint8)
+    perm = torch.randperm(C, generator=gen, device=gpu)
+    meta = {"qweight": q, "scale": scale, "qzero": zero, "perm_inv": torch.argsort(perm).to(torch.int16),
+            "group_sizes": torch.full([C // gsz], gsz, dtype=torch.int16),
+            "group_bit_widths": torch.full([C // gsz], 4, dtype=torch.uint8)}
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu)
+    w = amd.quant.reconstruct_weight(meta, torch.float16, gpu)
+    x = torch.randn(m, C, generator=gen, device=gpu).half()
+    y = layer(x)
+    assert y.shape == (m, r)
+    rows = torch.cat([torch.tensor([0, 255, 256, m - 1], device=gpu), torch.randint(0, m, (124,), generator=gen, device=gpu)])
+    cols = torch.cat([torch.tensor([0, 255, 256, r - 1], device=gpu), torch.randint(0, r, (508,), generator=gen, device=gpu)])
+    ref = x[rows].double() @ w[cols].double().t()
+    got = y[rows][:, cols].double()
+    # fp32 accumulation of exact fp16 products over K = 11008, one fp16 rounding of the result
+    assert (got - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
+    # every row and column was written: the column sums of y against those of the reference product
+    colsum = y.double().sum(dim=0)
+    ref_colsum = x.double().sum(dim=0) @ w.double().t()
+    assert (colsum - ref_colsum).abs().max() <= 1e-3 * ref.abs().max() * m ** 0.5 + 1e-2
