@@ -29,6 +29,9 @@ SIGNATURES = {
     "gq_hessian_invert_workspace": (c_size_t, [c_int64]),
     "gq_hessian_invert": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
                                   c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "gq_hessian_invert_static_max_c": (c_int64, []),
+    "gq_hessian_invert_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
+                                         c_int, ctypes.POINTER(c_int), c_void_p]),
     "gq_find_params": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                c_void_p]),
     "gq_quantize_range": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,

@@ -13,6 +13,7 @@
 //                   (L22, L22^-1) = rec(D);   (L^-1)21 = -L22^-1 (L21 L11^-1)
 // whose products run on the fp32 MFMA GEMM (sgemm.hip) and whose 128x128 leaves are factored and
 // inverted inside one workgroup in LDS.
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -594,4 +595,55 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
 {
     return invert_impl(hessian, hessian_inv, perm, perm_inv, c, n_samples, damp_ratio, act_order, max_try, workspace,
                        workspace_bytes, tries_host, (hipStream_t)stream_, "gq_hessian_invert");
+}
+
+// ---- the same call without any allocation -----------------------------------------------------
+// For callers that cannot allocate device memory (harnesses that forbid it, tight loops): the
+// workspace gq_hessian_invert takes from its caller lives in a file-scope device array instead.
+// Each GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; host code never uses the array's name as an address, only the pointer that
+// hipGetSymbolAddress returned for the device that is current.
+namespace {
+
+constexpr int64_t STATIC_MAX_C = 1024;
+// carve() for C = 1024: three C x C fp32 matrices, three C-long vectors, three 256-byte words
+constexpr size_t STATIC_SCRATCH_BYTES = 3 * (size_t)STATIC_MAX_C * STATIC_MAX_C * 4 + 3 * (size_t)STATIC_MAX_C * 4 + 3 * 256;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[MAX_DEVICES] = {};
+
+// the device-side address of `scratch` on the current device (looked up once per device)
+int scratch_for_current_device(void **out)
+{
+    int device = 0;
+    GQ_HIP(hipGetDevice(&device));
+    GQ_REQUIRE(device >= 0 && device < MAX_DEVICES, "gq_hessian_invert_static: device index %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        GQ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        GQ_REQUIRE(p != nullptr, "gq_hessian_invert_static: no device address for the scratch array");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return GQ_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t gq_hessian_invert_static_max_c(void) { return STATIC_MAX_C; }
+
+extern "C" int gq_hessian_invert_static(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c,
+                                        double n_samples, float damp_ratio, int act_order, int max_try,
+                                        int *tries_host, gq_stream_t stream_)
+{
+    GQ_REQUIRE(c > 0 && c <= STATIC_MAX_C, "gq_hessian_invert_static: C = %lld, at most %lld fit the built-in workspace "
+               "(use gq_hessian_invert with a workspace of your own)", (long long)c, (long long)STATIC_MAX_C);
+    void *ws = nullptr;
+    int rc = scratch_for_current_device(&ws);
+    if (rc) return rc;
+    return invert_impl(hessian, hessian_inv, perm, perm_inv, c, n_samples, damp_ratio, act_order, max_try, ws,
+                       STATIC_SCRATCH_BYTES, tries_host, (hipStream_t)stream_, "gq_hessian_invert_static");
 }

@@ -86,6 +86,21 @@ int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t
                       int64_t c, double n_samples, float damp_ratio, int act_order, int max_try,
                       void *workspace, size_t workspace_bytes, int *tries_host, gq_stream_t stream);
 
+/* gq_hessian_invert without a workspace argument and without any allocation: the workspace is a
+ * device array built into the library (about 12.6 MB on every GPU the library runs on, held until
+ * the process ends), so C is limited to gq_hessian_invert_static_max_c() = 1024 (larger C:
+ * GQ_EINVAL).  Same arguments otherwise, same kernels, same results bit for bit.  The call issues
+ * no hipMalloc / hipFree; it still synchronises the stream once per try, like gq_hessian_invert.
+ * All calls on one GPU share the one array: calls that overlap in time on the same GPU (from two
+ * streams or two threads) race and must be serialised by the caller.
+ * No counterpart in the reference: it exists for callers that cannot allocate device memory
+ * (harnesses that forbid allocation, tight loops around small layers such as OPT-125M's 768-wide
+ * Hessians). */
+int64_t gq_hessian_invert_static_max_c(void);
+int gq_hessian_invert_static(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv,
+                             int64_t c, double n_samples, float damp_ratio, int act_order, int max_try,
+                             int *tries_host, gq_stream_t stream);
+
 /* Per-row quantisation grid over columns [col0, col0+ncols) of W^T stored as weights_t[C][R]:
  * asymmetric (sym = 0): scale = (max(x,0) - min(x,0)) / maxq + 1e-12, qzero = round(-min/scale);
  * symmetric: scale = max|x| * 2/maxq + 1e-12, qzero = (maxq+1)/2.   maxq = 2^bits - 1.
