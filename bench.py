@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Benchmark of the GPTQ hot path at the Llama-2-7B configuration (4-bit, g=128, act-order,
+"""Benchmark of the GPTQ hot path (default: the Llama-2-7B configuration -- 4-bit, g=128, act-order,
 128 calibration sequences of 2048 tokens), synthetic activations and weights of the real shapes.
 
 One step = the hot path of ONE decoder block, in the order the reference's driver runs it
@@ -8,34 +8,42 @@ One step = the hot path of ONE decoder block, in the order the reference's drive
     HessianHook.invert                                   (Cholesky-inverse factor U)
     for each Linear of the set:
         gptq_quant (native-loop semantics)               (column loop + trailing fp32 GEMMs)
-        reconstruct_nn_linear                            (dense fp16 weight, as the reference keeps)
-        QuantLinear.pack
-    replay of all batches through the packed Linears of the set (W4A16 GEMM: llama.py:176-177)
-The reported value is the wall-clock of the 32-block model: ms_per_step * 32 (all blocks have the
+        reconstruct_nn_linear                            (dense 16-bit weight, as the reference keeps)
+        QuantLinear.pack                                 (the packed serving form)
+    replay of all batches through the reconstructed Linears of the set (llama.py:176-177: dense
+    x W^T on the reconstructed weight, on this library's own MFMA kernel)
+The reported value is the wall-clock of the whole model: ms_per_step * blocks (all blocks have the
 same shapes).  Inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run): calibration samples are split over ranks, H is
-all-reduced over RCCL, every rank inverts, rows of each Linear are split over ranks and
-all-gathered, each rank replays its own samples: strong scaling of the same job.
+`serving` (rank 0, outside the timed region): QuantLinear.forward -- the packed int4 x fp16 GEMM --
+of the 7 Linears of a block at seq 2048 x batch 1 and 8.
+
+N > 1: one process per GPU (launched by torch.distributed.run, or by this script itself when it is
+started plainly with --gpus N).  Calibration samples are split over ranks, the lower triangle of H
+is reduce-scattered and all-gathered over RCCL, every rank inverts, rows of each Linear are split
+over ranks and all-gathered, each rank replays its own samples: strong scaling of the same job.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HIDDEN, FFN, SEQ = 4096, 11008, 2048
-N_BLOCKS = 32
-# (in_features, [out_features of the Linears sharing that input])
-SETS = [(HIDDEN, [HIDDEN, HIDDEN, HIDDEN]), (HIDDEN, [HIDDEN]), (HIDDEN, [FFN, FFN]), (FFN, [HIDDEN])]
+SEQ = 2048
+# hidden, ffn, rows of k / v (grouped-query attention in 70B), decoder blocks
+MODELS = {
+    "7b": dict(name="Llama-2-7B", hidden=4096, ffn=11008, kv=4096, blocks=32),
+    "13b": dict(name="Llama-2-13B", hidden=5120, ffn=13824, kv=5120, blocks=40),
+    "70b": dict(name="Llama-2-70B", hidden=8192, ffn=28672, kv=1024, blocks=80),
+}
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of MI355X
+MERGE_ROWS = 16384              # Linears of a set are replayed in one launch up to this many rows in all
 
 
 def parse():
@@ -43,14 +51,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", choices=sorted(MODELS), default="7b")
+    ap.add_argument("--bits", type=int, choices=(3, 4), default=4)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "xtx_traffic.json"),
-                    help="per-launch HBM bytes of the XtX kernel from a rocprofv3 --pmc run, if present")
-    ap.add_argument("--w4-traffic-json", default=os.path.join(ROOT, "profiles", "w4a16_traffic.json"),
-                    help="per-launch HBM bytes of the W4A16 kernel from a rocprofv3 --pmc run, if present")
+    ap.add_argument("--no-serving", action="store_true")
+    ap.add_argument("--replay", choices=("dense", "packed"), default="dense",
+                    help="dense: x W^T on the reconstructed weight (what the reference runs); packed: the W4A16 GEMM")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "gemm_nt_traffic.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run, if present")
     return ap.parse_args()
+
+
+def sets_of(model):
+    h, f, kv = model["hidden"], model["ffn"], model["kv"]
+    # (in_features, [out_features of the Linears sharing that input])
+    return [(h, [h, kv, kv]), (h, [h]), (h, [f, f]), (f, [h])]
+
+
+def self_launch(args):
+    """Started plainly with --gpus N > 1: become the launcher.  Nothing has touched the GPU yet (torch
+    is not even imported), so the ranks are ordinary child processes of this one."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 class Phase:
@@ -60,6 +87,7 @@ class Phase:
         self.pairs = []
 
     def __enter__(self):
+        import torch
         self.s = torch.cuda.Event(enable_timing=True)
         self.e = torch.cuda.Event(enable_timing=True)
         self.s.record()
@@ -76,25 +104,22 @@ class Phase:
         return len(self.pairs)
 
 
-def make_inputs(dev, n_local, seed):
+def make_inputs(torch, dev, sets, n_local, seed):
     gen = torch.Generator(device=dev).manual_seed(seed)
     xs = {}
-    for c in (HIDDEN, FFN):
+    for c in sorted({c for c, _ in sets}):
         x = torch.empty(n_local, SEQ, c, dtype=torch.float16, device=dev)
         colscale = 1.0 + 3.0 * torch.arange(c, device=dev) / c
         for i in range(0, n_local, 4):
             x[i:i + 4] = (torch.randn(x[i:i + 4].shape, generator=gen, device=dev) * colscale).half()
         xs[c] = x
     ws = []
-    for c, outs in SETS:
+    for c, outs in sets:
         ws.append([(torch.randn(r, c, generator=gen, device=dev) * 0.02).half() for r in outs])
     return xs, ws
 
 
 VERBOSE = bool(os.environ.get("GQ_BENCH_VERBOSE"))
-if VERBOSE:   # a stuck rank shows where: Python stacks of all threads every two minutes
-    import faulthandler
-    faulthandler.dump_traceback_later(120, repeat=True, file=sys.stderr)
 
 
 def note(rank, msg):
@@ -102,10 +127,11 @@ def note(rank, msg):
         print("[rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
 
-def run_block(amd, gd, xs, ws, batch, phases, rank, world):
+def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
     """The hot path of one decoder block on this rank's share of samples and rows."""
-    dev = xs[HIDDEN].device
-    for (c, outs), weights in zip(SETS, ws):
+    dev = next(iter(xs.values())).device
+    batch = args.batch
+    for (c, outs), weights in zip(sets, ws):
         note(rank, "set C=%d" % c)
         x = xs[c]
         hook = amd.HessianHook()
@@ -113,98 +139,173 @@ def run_block(amd, gd, xs, ws, batch, phases, rank, world):
             with phases["xtx_%d" % c]:
                 hook.add_batch(x[bi:bi + batch])
         if world > 1:
-            note(rank, "allreduce")
             with phases["allreduce"]:
                 hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
-        note(rank, "invert")
         with phases["invert"]:
             hook.invert(damp_ratio=1e-2, act_order=True)
         gs = torch.full([c // 128], 128, dtype=torch.int32)
-        gb = torch.full([c // 128], 4, dtype=torch.int32)
-        layers = []
+        gb = torch.full([c // 128], args.bits, dtype=torch.int32)
         shards = [gd.row_shard(w.shape[0], rank, world) for w in weights]
         with phases["quant"]:
             # the Linears of the set share U: all of them are enqueued (row slices on side streams)
             # before the first result is waited for
-            results = amd.gptq_quant_set([w[rb:re] for w, (rb, re) in zip(weights, shards)], hook, gs, gb,
-                                         scale_bit_width=None, gptq_use_kernel=True, gptq_block_sizes=gs,
-                                         quant_symmetric=False, quant_mse=False, save_device=dev)
-        if VERBOSE:
-            torch.cuda.synchronize()
-            note(rank, "quantised")
-        for w, res in zip(weights, results):
-            r = w.shape[0]
-            meta = res["quant_meta"]
+            mine = [(i, w[rb:re]) for i, (w, (rb, re)) in enumerate(zip(weights, shards)) if re > rb]
+            part = amd.gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
+                                      gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev)
+            by_index = {i: res for (i, _), res in zip(mine, part)}
+        dense, packed = [], []
+        for i, w in enumerate(weights):
+            res = by_index.get(i)
             if world > 1:
-                note(rank, "allgather")
                 with phases["allgather"]:
-                    full = gd.allgather_rows({k: meta[k] for k in ("qweight", "scale", "qzero")}, r)
-                    meta = dict(meta, **full)
-            note(rank, "reconstruct + pack")
+                    fields = {"qscale": None, "sscale": None, "scale_bit_width": None,
+                              "perm_inv": hook.perm_inv.to(torch.int16), "group_sizes": gs.to(torch.int16).to(dev),
+                              "group_bit_widths": gb.to(torch.uint8).to(dev)}
+                    res = gd.gather_quant_result(res, fields, w.shape[0], c, w.dtype, dev)
+            meta = res["quant_meta"]
             with phases["reconstruct"]:
-                lin = amd.reconstruct_nn_linear(meta, dtype=torch.float16, device=dev)
-                del lin
+                dense.append(amd.quant.reconstruct_weight(meta, torch.float16, dev))
             with phases["pack"]:
-                layers.append(amd.QuantLinear.from_quant_meta(meta, dev))
+                packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True))
+            del meta, res
+        del part, by_index
+        # replay (llama.py:176-177).  Dense: the Linears of a set read the same input, so up to MERGE_ROWS
+        # rows of reconstructed weights are stacked and replayed in one launch per batch (each output row
+        # is the same dot product either way).  Packed: one gather of the batch into act-order per set,
+        # then the W4A16 GEMM per Linear.
+        if args.replay == "dense":
+            if len(dense) > 1 and sum(w.shape[0] for w in dense) <= MERGE_ROWS:
+                with phases["reconstruct"]:
+                    dense = [torch.cat(dense, dim=0)]
+            for bi in range(0, x.shape[0], batch):
+                x2 = x[bi:bi + batch].reshape(-1, c)
+                for w in dense:
+                    with phases["replay_gemm"]:
+                        y = amd.ops.gemm_nt(x2, w)
+                    flops[0] += 2.0 * x2.shape[0] * w.shape[0] * c
+                    del y
+        else:
+            for bi in range(0, x.shape[0], batch):
+                with phases["permute"]:
+                    xp = packed[0].permute_input(x[bi:bi + batch])
+                for layer in packed:
+                    with phases["replay_gemm"]:
+                        y = layer.forward_permuted(xp)
+                    flops[0] += 2.0 * xp.shape[0] * xp.shape[1] * layer.out_features * c
+                    del y
+                del xp
+        del dense, packed, hook
+
+
+def serving(torch, amd, sets, bits, dev):
+    """QuantLinear.forward (activation gather + W4A16 GEMM) of the 7 Linears of a block at seq 2048 x
+    batch 1 and 8, random levels / scales / act-order of the real shapes."""
+    gen = torch.Generator(device=dev).manual_seed(7)
+    layers = []
+    for c, outs in sets:
+        for r in outs:
+            meta = {"qweight": torch.randint(0, 1 << bits, (r, c), generator=gen, device=dev, dtype=torch.uint8),
+                    "scale": (torch.rand(r, c // 128, generator=gen, device=dev) * 0.01 + 0.002).half(),
+                    "qzero": torch.randint(0, 1 << bits, (r, c // 128), generator=gen, device=dev, dtype=torch.uint8),
+                    "perm_inv": torch.argsort(torch.randperm(c, generator=gen, device=dev)).to(torch.int16),
+                    "group_sizes": torch.full([c // 128], 128, dtype=torch.int16),
+                    "group_bit_widths": torch.full([c // 128], bits, dtype=torch.uint8)}
+            layers.append((c, r, amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True)))
             del meta
-        del results
-        # replay (llama.py:176-177): the Linears of a set share the input and its act-order, so each
-        # batch is gathered into permuted column order once and fed to every layer of the set
-        note(rank, "replay")
-        for bi in range(0, x.shape[0], batch):
-            with phases["permute"]:
-                xp = layers[0].permute_input(x[bi:bi + batch])
-            for layer in layers:
-                with phases["w4a16"]:
-                    y = layer.forward_permuted(xp)
-                del y
-            del xp
-        del layers
-        del hook
+    out = {}
+    for batch in (1, 8):
+        m = batch * SEQ
+        xin = {c: torch.randn(m, c, generator=gen, device=dev).half() for c in {c for c, _, _ in layers}}
+        flops = sum(2.0 * m * r * c for c, r, _ in layers)
+        for _ in range(2):
+            for c, r, layer in layers:
+                layer(xin[c])
+        torch.cuda.synchronize()
+        reps = 10
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            for c, r, layer in layers:
+                layer(xin[c])
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        # the GEMMs alone (input already in act-order), for the matrix-pipe figure
+        xp = {c: xin[c] for c in xin}
+        s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s2.record()
+        for _ in range(reps):
+            for c, r, layer in layers:
+                layer.forward_permuted(xp[c])
+        e2.record()
+        torch.cuda.synchronize()
+        ms_gemm = s2.elapsed_time(e2) / reps
+        tf = flops / (ms_gemm * 1e-3) / 1e12
+        out["seq2048_batch%d" % batch] = {"tokens": m, "block_forward_ms": round(ms, 4), "w4a16_gemm_ms": round(ms_gemm, 4),
+                                          "w4a16_tflops": round(tf, 1),
+                                          "frac_of_f16_mfma_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+        del xin, xp
+    return out
 
 
-def cpu_baseline():
+def cpu_baseline(sets, n_blocks, n_seq, bits):
     """The reference's pure-PyTorch CPU path (gptq_py.py: add_batch(use_kernel=False), invert,
-    gptq_quant(gptq_use_kernel=False)) as restated in oracle/, timed on this host on a bounded
-    sample and extrapolated to the 32-block model by flop ratios."""
+    gptq_quant(gptq_use_kernel=False)) as restated in oracle/, timed on this host's cores on a
+    bounded sample of the same workload: one sequence per Hessian width, one inversion per width,
+    a slice of rows per layer width; scaled by the counts of sequences, inversions and rows (the
+    loops are linear in those), not across sizes."""
+    import torch
     from oracle import gptq_oracle as oracle
     cores = torch.get_num_threads()
     gen = torch.Generator().manual_seed(0)
-    c, r = HIDDEN, 1024
-    x = (torch.randn(1, SEQ, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half()
-    w = (torch.randn(r, c, generator=gen) * 0.02).half()
-    hook = oracle.OracleHessian()
-    t0 = time.perf_counter()
-    hook.add_batch(x)
-    t_add = time.perf_counter() - t0          # one 2048-token sequence, C = 4096
-    t0 = time.perf_counter()
-    hook.invert(1e-2, True)
-    t_inv = time.perf_counter() - t0          # C = 4096
-    gs = torch.full([c // 128], 128, dtype=torch.int32)
-    gb = torch.full([c // 128], 4, dtype=torch.int32)
-    t0 = time.perf_counter()
-    oracle.gptq_quant(w, hook, gs, gb, use_kernel_semantics=False, block_sizes=gs)
-    t_q = time.perf_counter() - t0            # 1024 x 4096 layer, python-loop semantics
-    k = FFN / HIDDEN
-    n_seq = 128
-    per_block = (3 * n_seq * t_add + n_seq * t_add * k * k          # Hessians: 2*T*C^2
-                 + 3 * t_inv + t_inv * k ** 3                        # inversions: ~C^3
-                 + t_q * (4 * 4 + 2 * 4 * k + 4 * k * k))            # column loops: ~R*C^2 from a 1024 x 4096 sample
-    return {"value": round(per_block * N_BLOCKS, 1), "unit": "s", "cores": cores, "kind": "port",
-            "sample": ("measured: add_batch of one 2048x4096 sequence %.3f s, invert C=4096 %.2f s, "
-                       "gptq_quant (PyTorch-loop semantics) of a 1024x4096 layer %.2f s; extrapolated to "
-                       "32 blocks x (4 Hessians of 128 sequences, 4 inversions, 7 Linears) by flop ratios; "
-                       "the replay GEMMs are not part of gptq_py.py and are not in this figure"
-                       % (t_add, t_inv, t_q))}
+    widths = sorted({c for c, _ in sets})
+    t_add, t_inv, t_row = {}, {}, {}
+    sample_rows = {}
+    for c in widths:
+        x = (torch.randn(1, SEQ, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half()
+        hook = oracle.OracleHessian()
+        t0 = time.perf_counter()
+        hook.add_batch(x)
+        t_add[c] = time.perf_counter() - t0
+        # a full-rank Hessian for the inversion and the loop: more tokens than columns, cheaply
+        for _ in range((c + SEQ - 1) // SEQ + 1):
+            hook.add_batch((torch.randn(1, SEQ, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half())
+        t0 = time.perf_counter()
+        hook.invert(1e-2, True)
+        t_inv[c] = time.perf_counter() - t0
+        rows = max(16, min(256, (1 << 22) // c // 16 * 16))
+        w = (torch.randn(rows, c, generator=gen) * 0.02).half()
+        gs = torch.full([c // 128], 128, dtype=torch.int32)
+        gb = torch.full([c // 128], bits, dtype=torch.int32)
+        t0 = time.perf_counter()
+        oracle.gptq_quant(w, hook, gs, gb, use_kernel_semantics=False, block_sizes=gs)
+        t_row[c] = (time.perf_counter() - t0) / rows
+        sample_rows[c] = rows
+        del hook, x, w
+    per_block = 0.0
+    for c, outs in sets:
+        per_block += n_seq * t_add[c] + t_inv[c] + sum(outs) * t_row[c]
+    sample = "; ".join("C=%d: add_batch of one 2048-token sequence %.3f s, invert %.2f s, gptq_quant (PyTorch-loop semantics) "
+                       "of %d rows %.2f s" % (c, t_add[c], t_inv[c], sample_rows[c], t_row[c] * sample_rows[c]) for c in widths)
+    return {"value": round(per_block * n_blocks, 1), "unit": "s", "cores": cores, "kind": "port",
+            "sample": "measured on this host -- " + sample + "; scaled to %d blocks x (4 Hessians of %d sequences, 4 inversions, "
+                      "7 Linears) by sequence and row counts; the replay GEMMs are not part of gptq_py.py and are not in this figure"
+                      % (n_blocks, n_seq)}
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if VERBOSE:   # a stuck rank shows where: Python stacks of all threads every two minutes
+        import faulthandler
+        faulthandler.dump_traceback_later(120, repeat=True, file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # GQ_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share
@@ -224,9 +325,14 @@ def main():
     import gptq_v2_amd as amd
     from gptq_v2_amd import dist as gd
 
+    model = MODELS[args.model]
+    sets = sets_of(model)
+    n_blocks = model["blocks"]
     sb, se = gd.sample_shard(args.samples, rank, world)
-    xs, ws = make_inputs(dev, se - sb, seed=1234)   # same seed on every rank: same weights
-    names = ["xtx_%d" % HIDDEN, "xtx_%d" % FFN, "allreduce", "invert", "quant", "allgather", "reconstruct", "pack", "permute", "w4a16"]
+    xs, ws = make_inputs(torch, dev, sets, se - sb, seed=1234)   # same seed on every rank: same weights
+    widths = sorted({c for c, _ in sets})
+    names = ["xtx_%d" % c for c in widths] + ["allreduce", "invert", "quant", "allgather", "reconstruct", "pack", "permute",
+                                               "replay_gemm"]
 
     def sync():
         if world > 1:
@@ -234,13 +340,15 @@ def main():
         torch.cuda.synchronize()
 
     phases = {n: Phase() for n in names}
+    flops = [0.0]
     for _ in range(args.warmup):
-        run_block(amd, gd, xs, ws, args.batch, phases, rank, world)
+        run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops)
     sync()
     phases = {n: Phase() for n in names}
+    flops = [0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_block(amd, gd, xs, ws, args.batch, phases, rank, world)
+        run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -250,30 +358,29 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
 
     if rank == 0:
-        breakdown = {n: round(p.total_ms() / max(args.steps, 1), 3) for n, p in phases.items() if p.count()}
+        steps = max(args.steps, 1)
+        breakdown = {n: round(p.total_ms() / steps, 3) for n, p in phases.items() if p.count()}
+
         def pmc_bytes(path):
             try:
                 return json.load(open(path)).get("hbm_bytes_per_launch")
             except Exception:
                 return None
 
-        # second kernel by share of the step: the XtX MFMA kernel at C = 4096 (one launch per add_batch call)
-        px = phases["xtx_%d" % HIDDEN]
+        hidden = model["hidden"]
+        px = phases["xtx_%d" % hidden]
         t_call = px.total_ms() / max(px.count(), 1) * 1e-3
         tokens_call = min(args.batch, se - sb) * SEQ
-        flops_call = 2.0 * tokens_call * HIDDEN * HIDDEN        # full product, as the algorithmic figure counts it
-        achieved = flops_call / t_call / 1e12 if t_call > 0 else 0.0
-        traffic = pmc_bytes(args.traffic_json)
-        # dominant kernel (about half of the step's GPU time): the W4A16 GEMM of the replay, one launch
-        # per Linear and batch; flops and duration are means over the 7 Linear shapes of the block
-        pw = phases["w4a16"]
-        local_tokens = (se - sb) * SEQ
-        w4_flops = sum(2.0 * local_tokens * r * c for c, outs in SETS for r in outs) * args.steps
-        w4_tflops = w4_flops / (pw.total_ms() * 1e-3) / 1e12 if pw.count() else 0.0
-        w4_launch_ms = pw.total_ms() / max(pw.count(), 1)
+        xtx_tflops = 2.0 * tokens_call * hidden * hidden / t_call / 1e12 if t_call > 0 else 0.0   # full product, as the algorithmic figure counts it
+        # dominant kernel: the replay GEMM; algorithmic flops 2 M R C per launch and launch duration,
+        # both as means over the launches of a block
+        pr = phases["replay_gemm"]
+        replay_tflops = flops[0] / (pr.total_ms() * 1e-3) / 1e12 if pr.count() else 0.0
+        replay_kernel = "gemm_nt_kernel (y = x W^T on the reconstructed fp16 weight" if args.replay == "dense" else \
+                        "w4a16_256_kernel (y = x W4^T"
         line = {
-            "metric": "llama2_7b_w4g128_quantize_wallclock",
-            "value": round(ms_per_step * N_BLOCKS / 1e3, 3),
+            "metric": "llama2_%s_w%dg128_quantize_wallclock" % (args.model, args.bits),
+            "value": round(ms_per_step * n_blocks / 1e3, 3),
             "unit": "s",
             "n_gpus": world,
             "steps": args.steps,
@@ -284,26 +391,39 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": "Llama-2-7B 4-bit g=128 act-order, %d calib sequences x 2048 tokens, "
+            "config": {"workload": "%s %d-bit g=128 act-order, %d calib sequences x 2048 tokens, "
                                    "1 step = hot path of one decoder block (4 Hessians, 4 inversions, 7 Linears "
-                                   "quantised, reconstructed, packed and replayed through the W4A16 GEMM); "
-                                   "value = 32 blocks" % args.samples,
+                                   "quantised, reconstructed, packed, and replayed as %s GEMMs); "
+                                   "value = %d blocks" % (model["name"], args.bits, args.samples, args.replay, n_blocks),
                        "batch": args.batch, "parallelism": "dp%d samples + row-sharded quantize" % world},
-            "int4_gemm_tflops": round(w4_tflops, 1),
-            "int4_gemm_frac_of_f16_mfma_peak": round(w4_tflops / MFMA_F16_PEAK_TFLOPS, 4),
             "breakdown_ms_per_step": breakdown,
-            "roofline": {"kernel": "w4a16_256_kernel (y = x W4^T, %d tokens per launch, mean of the 7 Linears of a block)" % tokens_call,
-                         "bound": "mfma", "achieved": round(w4_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(w4_tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_bytes(args.w4_traffic_json), "avg_launch_ms": round(w4_launch_ms, 4),
-                         "launches": pw.count()},
-            "roofline_xtx": {"kernel": "xtx256_kernel (H += X^T X, C=4096, %d tokens per launch)" % tokens_call,
-                             "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"kernel": "%s, %d tokens per launch, mean of the launches of a block)" % (replay_kernel, tokens_call),
+                         "bound": "mfma", "achieved": round(replay_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(replay_tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                         "traffic": pmc_bytes(args.traffic_json),
+                         "avg_launch_ms": round(pr.total_ms() / max(pr.count(), 1), 4),
+                         "avg_launch_flops": round(flops[0] / max(pr.count(), 1), 1), "launches": pr.count()},
+            "roofline_xtx": {"kernel": "xtx256_kernel (H += X^T X, C=%d, %d tokens per launch)" % (hidden, tokens_call),
+                             "bound": "mfma", "achieved": round(xtx_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(xtx_tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                             "traffic": pmc_bytes(os.path.join(ROOT, "profiles", "xtx_traffic.json")),
                              "avg_launch_ms": round(t_call * 1e3, 4)},
         }
+        if world > 1:
+            h_bytes = sum(4.0 * c * c for c, _ in sets)
+            line["collectives"] = {"allreduce_ms_per_step": breakdown.get("allreduce"),
+                                   "allgather_ms_per_step": breakdown.get("allgather"),
+                                   "hessian_bytes_per_step": h_bytes,
+                                   "allreduce_algorithmic_GBps": round(h_bytes / max(breakdown.get("allreduce", 0.0), 1e-9) / 1e6, 1)}
+        del xs, ws
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_serving:
+            line["serving"] = serving(torch, amd, sets, args.bits, dev)
+            best = line["serving"]["seq2048_batch8"]
+            line["int4_gemm_tflops"] = best["w4a16_tflops"]
+            line["int4_gemm_frac_of_f16_mfma_peak"] = best["frac_of_f16_mfma_peak"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(sets, n_blocks, args.samples, args.bits)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -10,9 +10,9 @@ _lib.load()
 from . import ops  # noqa: E402
 from .gptq_py import GPTQ, HessianHook, gptq_quant, gptq_quant_set  # noqa: E402
 from .native import accumulate_hessian, accumulate_hessian_triton, gptq_quantize_range  # noqa: E402
-from .quant import (QuantLinear, Quantizer, collate_quantizers, construct_matrix, dequantize,  # noqa: E402
+from .quant import (HipLinear, QuantLinear, Quantizer, collate_quantizers, construct_matrix, dequantize,  # noqa: E402
                     quantize, reconstruct_nn_linear)
 
 __all__ = ["ops", "GPTQ", "HessianHook", "gptq_quant", "gptq_quant_set", "accumulate_hessian", "accumulate_hessian_triton",
-           "gptq_quantize_range", "QuantLinear", "Quantizer", "collate_quantizers", "construct_matrix",
+           "gptq_quantize_range", "HipLinear", "QuantLinear", "Quantizer", "collate_quantizers", "construct_matrix",
            "dequantize", "quantize", "reconstruct_nn_linear"]

@@ -60,6 +60,7 @@ SIGNATURES = {
                               c_int, c_void_p]),
     "gq_w4a16_gemm_dt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                  c_int, c_int, c_void_p]),
+    "gq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

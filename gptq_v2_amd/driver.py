@@ -25,7 +25,7 @@ from torch import nn
 
 from . import dist as gd
 from .gptq_py import HessianHook, gptq_quant_set
-from .quant import QuantLinear, reconstruct_weight
+from .quant import HipLinear, QuantLinear, reconstruct_weight
 
 # Linears of one Llama decoder block in dependency order; each inner list shares its input.
 LLAMA_SETS: List[List[str]] = [
@@ -207,12 +207,17 @@ def quantize_llama(
             meta = res["quant_meta"]
             results["metrics"][canonical] = res["metrics"]
             results["data"][canonical] = _to_device(meta, torch.device("cpu"))
+            parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
             if pack:
-                layer = QuantLinear.from_quant_meta(meta, device)
-                parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
-                setattr(parent, name.rsplit(".", 1)[-1], layer)
+                layer = QuantLinear.from_quant_meta(meta, device, validate=False, has_perm=bool(act_order))
+            elif mod.bias is None:
+                # the dense reconstructed weight the reference leaves in the model, in an nn.Linear whose
+                # forward (the replay of the calibration batches) runs this library's dense MFMA kernel
+                layer = HipLinear.from_weight(reconstruct_weight(meta, dtype, device))
             else:
                 mod.weight.data = reconstruct_weight(meta, dtype, device)
+                layer = mod
+            setattr(parent, name.rsplit(".", 1)[-1], layer)
 
     def run_until(block, name, hook, keep=None):
         """forward of every batch up to the input of sub-module `name`: into the Hessian, and into

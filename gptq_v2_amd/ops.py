@@ -321,3 +321,24 @@ def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Ten
                                               int(group_size), code, _stream(x))
     _lib.check(rc, "gq_w4a16_gemm")
     return y
+
+
+def gemm_nt(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """x (M, K) @ weight (N, K)^T -> (M, N), fp16 or bf16, fp32 accumulation: the dense Linear forward
+    of the calibration replay (llama.py:176-177) on the hand-written MFMA kernel."""
+    _check(x, "x", None, 2)
+    _check(weight, "weight", x.dtype, 2)
+    code = _dtype_code(x)
+    m, k = x.shape
+    n = weight.shape[0]
+    if weight.shape[1] != k:
+        raise ValueError(f"gemm_nt: x has {k} columns, weight has {weight.shape[1]}")
+    if k % 64:
+        raise NotImplementedError("gemm_nt: in_features must be a multiple of 64")
+    if x.device != weight.device:
+        raise ValueError("gemm_nt: x and weight are on different devices")
+    y = torch.empty(m, n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_gemm_nt(_p(y), _p(x), _p(weight), m, n, k, code, _stream(x))
+    _lib.check(rc, "gq_gemm_nt")
+    return y

@@ -189,6 +189,31 @@ def reconstruct_weight(quant_meta: dict, dtype: torch.dtype, device) -> torch.Te
     return ops.dequantize(qweight, scale, qzero, perm_inv, gs)
 
 
+class HipLinear(nn.Linear):
+    """An ``nn.Linear`` without bias whose forward runs the hand-written dense MFMA kernel
+    (``gq_gemm_nt``) when it can: 16-bit weight on a GPU, in_features a multiple of 64.  Anything
+    else takes ``nn.Linear``'s own forward.  Same parameters and state dict as ``nn.Linear``; it is
+    the module the reference's replay ``lin(h)`` (llama.py:176-177) runs through here."""
+
+    @classmethod
+    def from_weight(cls, weight: torch.Tensor) -> "HipLinear":
+        with torch.device("meta"):
+            lin = cls(weight.shape[1], weight.shape[0], bias=False, dtype=weight.dtype)
+        lin.weight = nn.Parameter(weight, requires_grad=False)
+        lin.eval()
+        return lin
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        w = self.weight
+        if (self.bias is not None or w.device.type != "cuda" or w.dtype not in (torch.float16, torch.bfloat16)
+                or x.dtype != w.dtype or x.device != w.device or self.in_features % 64 or torch.is_grad_enabled() and
+                (x.requires_grad or w.requires_grad)):
+            return super().forward(x)
+        x2 = x.reshape(-1, self.in_features)
+        y = ops.gemm_nt(x2 if x2.is_contiguous() else x2.contiguous(), w.data if w.is_contiguous() else w.data.contiguous())
+        return y.reshape(*x.shape[:-1], self.out_features)
+
+
 def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.device = torch.device("cpu")) -> nn.Linear:
     """Dense ``nn.Linear`` (no bias) from a ``quant_meta`` dict (quant.py:262-279), placed on
     ``device`` (default CPU, as in the reference).  The dequantisation itself always runs on a GPU:
@@ -202,11 +227,7 @@ def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.de
     else:
         compute = torch.device("cuda", torch.cuda.current_device())
     weight = reconstruct_weight(quant_meta, dtype, compute).to(device)
-    with torch.device("meta"):
-        lin = nn.Linear(weight.shape[1], weight.shape[0], bias=False, dtype=dtype)
-    lin.weight = nn.Parameter(weight, requires_grad=False)
-    lin.eval()
-    return lin
+    return HipLinear.from_weight(weight)   # an nn.Linear; on a GPU its forward is the MFMA kernel of this library
 
 
 class QuantLinear(nn.Module):
@@ -237,7 +258,7 @@ class QuantLinear(nn.Module):
         self.register_buffer("perm", None)
 
     @classmethod
-    def from_quant_meta(cls, quant_meta: dict, device) -> "QuantLinear":
+    def from_quant_meta(cls, quant_meta: dict, device, validate: bool = True, has_perm: Optional[bool] = None) -> "QuantLinear":
         r, c = quant_meta["qweight"].shape
         gs = _group_list(quant_meta["group_sizes"])
         bits = set(_group_list(quant_meta["group_bit_widths"]))
@@ -245,24 +266,30 @@ class QuantLinear(nn.Module):
             raise NotImplementedError("QuantLinear needs one group size and one bit width")
         sdt = quant_meta["scale"].dtype   # the model's 16-bit type (gptq_py.py:218)
         layer = cls(c, r, gs[0], bits.pop(), sdt if sdt in (torch.float16, torch.bfloat16) else torch.float16)
-        layer.pack(quant_meta, device)
+        layer.pack(quant_meta, device, validate=validate, has_perm=has_perm)
         return layer
 
     @torch.no_grad()
-    def pack(self, quant_meta: dict, device=None) -> None:
+    def pack(self, quant_meta: dict, device=None, validate: bool = True, has_perm: Optional[bool] = None) -> None:
+        """``validate``: check that every level and zero point fits the bit width (one device-to-host
+        round trip; a caller that packs what ``gptq_quant`` has just produced can skip it).
+        ``has_perm``: whether ``perm_inv`` is a real permutation (True), the identity (False), or to be
+        looked at (None: one more round trip)."""
         device = device if device is not None else quant_meta["qweight"].device
         q = quant_meta["qweight"].to(device=device, dtype=torch.uint8).contiguous()
         if q.shape != (self.out_features, self.in_features):
             raise ValueError("quant_meta does not match this layer's shape")
         if self.in_features % 64:
             raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
-        if int(q.max()) >= (1 << self.bits) or int(quant_meta["qzero"].max()) >= (1 << self.bits):
-            raise ValueError(f"quant_meta holds values outside {self.bits} bits")
+        if validate:
+            worst = torch.maximum(q.max(), quant_meta["qzero"].to(device=device, dtype=torch.uint8).max())
+            if int(worst) >= (1 << self.bits):
+                raise ValueError(f"quant_meta holds values outside {self.bits} bits")
         self.qweight = ops.pack_rows(q, 4, ops.PACK_W4_KBLOCK)
         self.scales = meta_scale(quant_meta, self.dtype, device).t().contiguous()
         self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
         perm_inv = quant_meta.get("perm_inv")
-        if perm_inv is None:
+        if perm_inv is None or has_perm is False:
             self.perm = None
         else:
             pi = perm_inv.to(device=device, dtype=torch.int64)
@@ -270,7 +297,10 @@ class QuantLinear(nn.Module):
             # perm = argsort(perm_inv): scatter, exact because perm_inv is a permutation
             perm = torch.empty_like(pi)
             perm[pi] = ident
-            self.perm = None if torch.equal(pi, ident) else perm.to(torch.int32).contiguous()
+            if has_perm is None and torch.equal(pi, ident):
+                self.perm = None
+            else:
+                self.perm = perm.to(torch.int32).contiguous()
 
     @torch.no_grad()
     def unpack(self) -> dict:

@@ -242,6 +242,14 @@ int gq_w4a16_gemm_dt(void *y, const void *x, const uint32_t *qweight_packed, con
                      const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size,
                      int dtype, gq_stream_t stream);
 
+/* y[M][N] = x[M][K] * w[N][K]^T for dense 16-bit operands (dtype GQ_F16 or GQ_BF16 for all three),
+ * fp32 accumulation, one rounding of the result: the forward of the dense nn.Linear that the
+ * reference builds from a reconstructed weight and runs over the calibration batches
+ * (ref: llama.py:172-177 `lin(h)`, quant.py:276-278).  K must be a multiple of 64; M and N are
+ * free.  w is the output of gq_dequantize (columns in the model's own order, so x needs no gather). */
+int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int64_t n, int64_t k, int dtype,
+               gq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

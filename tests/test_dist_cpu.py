@@ -25,21 +25,42 @@ def _worker(rank, ws, port, n_rows):
     x = torch.randn(10, 6, c)                      # 10 calibration samples
     b, e = gd.sample_shard(10, rank, ws)
     xs = x[b:e].reshape(-1, c)
-    h = xs.t() @ xs
-    n = gd.allreduce_hessian(h, e - b)
-    assert n == 10
     full = x.reshape(-1, c)
-    assert torch.allclose(h, full.t() @ full, rtol=1e-5, atol=1e-4)
-    # every rank holds the same bits afterwards
-    hs = [torch.empty_like(h) for _ in range(ws)]
-    dist.all_gather(hs, h)
-    assert all(torch.equal(hs[0], t) for t in hs)
+    for algorithm, cc in (("direct", c), ("ring", c), ("direct", 30)):   # 30: a last row block that is not full
+        h = xs[:, :cc].t() @ xs[:, :cc]
+        h = torch.tril(h) + torch.tril(h, -1).t()      # exactly symmetric, as the XtX kernel leaves it
+        n = gd.allreduce_hessian(h, e - b, algorithm=algorithm)
+        assert n == 10
+        assert torch.allclose(h, full[:, :cc].t() @ full[:, :cc], rtol=1e-5, atol=1e-4)
+        assert torch.equal(h, h.t())
+        # every rank holds the same bits afterwards
+        hs = [torch.empty_like(h) for _ in range(ws)]
+        dist.all_gather(hs, h)
+        assert all(torch.equal(hs[0], t) for t in hs)
 
     rb, re = gd.row_shard(n_rows, rank, ws, multiple=4)
     q = torch.arange(n_rows * 5, dtype=torch.uint8).reshape(n_rows, 5)
     s = torch.arange(n_rows * 2, dtype=torch.float16).reshape(n_rows, 2)
     got = gd.allgather_rows({"qweight": q[rb:re], "scale": s[rb:re]}, n_rows, multiple=4)
     assert torch.equal(got["qweight"], q) and torch.equal(got["scale"], s)
+
+    # a Linear with fewer 64-row units than ranks: rank 1's shard is empty, it contributes the
+    # per-layer fields it can state itself and receives every row
+    rows, cols, g = 64, 8, 2
+    rb, re = gd.row_shard(rows, rank, ws)
+    assert (re - rb) == (64 if rank == 0 else 0)
+    fields = {"perm_inv": torch.arange(cols, dtype=torch.int16), "group_sizes": torch.tensor([4, 4], dtype=torch.int16),
+              "group_bit_widths": torch.tensor([4, 4], dtype=torch.uint8), "qscale": None, "sscale": None,
+              "scale_bit_width": None}
+    local = None
+    if re > rb:
+        meta = dict(fields, qweight=torch.full((rows, cols), 7, dtype=torch.uint8),
+                    scale=torch.full((rows, g), 0.5, dtype=torch.float16), qzero=torch.full((rows, g), 8, dtype=torch.uint8))
+        local = {"quant_meta": meta, "metrics": {"gptq_error": 1.0, "gptq_norm": 2.0, "l2.0_error": 3.0, "l2.0_norm": 4.0}}
+    res = gd.gather_quant_result(local, fields, rows, cols, torch.float16, "cpu")
+    assert res["quant_meta"]["qweight"].shape == (rows, cols) and int(res["quant_meta"]["qweight"].sum()) == 7 * rows * cols
+    assert torch.equal(res["quant_meta"]["perm_inv"], fields["perm_inv"])
+    assert res["metrics"] == {"gptq_error": 1.0, "gptq_norm": 2.0, "l2.0_error": 3.0, "l2.0_norm": 4.0}
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,3 +81,15 @@ def test_shards_cover_everything():
 def test_allreduce_and_allgather_world_size_2():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 26), nprocs=2, join=True)
+
+
+def test_pack_lower_roundtrip():
+    from gptq_v2_amd import dist as gd
+    for c in (4, 30, 32, 100, 257):
+        a = torch.randn(c, c)
+        h = torch.tril(a) + torch.tril(a, -1).t()
+        flat = gd.pack_lower(h, multiple=8)
+        assert flat.numel() % 8 == 0 and flat.numel() < c * c * 0.75 + 64
+        out = torch.full_like(h, float("nan"))
+        gd.unpack_lower(flat, out)
+        assert torch.equal(out, h)
