@@ -251,46 +251,48 @@ def serving(torch, amd, sets, bits, dev):
 def cpu_baseline(sets, n_blocks, n_seq, bits):
     """The reference's pure-PyTorch CPU path (gptq_py.py: add_batch(use_kernel=False), invert,
     gptq_quant(gptq_use_kernel=False)) as restated in oracle/, timed on this host's cores on a
-    bounded sample of the same workload: one sequence per Hessian width, one inversion per width,
-    a slice of rows per layer width; scaled by the counts of sequences, inversions and rows (the
-    loops are linear in those), not across sizes."""
+    bounded sample of the same workload: per Hessian width one 2048-token sequence of add_batch and
+    one inversion, per distinct Linear shape one whole gptq_quant (a row slice, stated, when the
+    layer is too large for the time budget).  The block's time is the sum over its own counts of
+    sequences, inversions and Linears; nothing is extrapolated across sizes."""
     import torch
     from oracle import gptq_oracle as oracle
     cores = torch.get_num_threads()
     gen = torch.Generator().manual_seed(0)
     widths = sorted({c for c, _ in sets})
-    t_add, t_inv, t_row = {}, {}, {}
-    sample_rows = {}
+    t_add, t_inv, t_layer, notes = {}, {}, {}, []
     for c in widths:
-        x = (torch.randn(1, SEQ, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half()
+        colscale = 1 + 3 * torch.arange(c) / c
+        x = (torch.randn(1, SEQ, c, generator=gen) * colscale).half()
         hook = oracle.OracleHessian()
         t0 = time.perf_counter()
         hook.add_batch(x)
         t_add[c] = time.perf_counter() - t0
-        # a full-rank Hessian for the inversion and the loop: more tokens than columns, cheaply
-        for _ in range((c + SEQ - 1) // SEQ + 1):
-            hook.add_batch((torch.randn(1, SEQ, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half())
+        for _ in range((c + SEQ - 1) // SEQ + 1):   # a full-rank Hessian for the inversion and the loop
+            hook.add_batch((torch.randn(1, SEQ, c, generator=gen) * colscale).half())
         t0 = time.perf_counter()
         hook.invert(1e-2, True)
         t_inv[c] = time.perf_counter() - t0
-        rows = max(16, min(256, (1 << 22) // c // 16 * 16))
-        w = (torch.randn(rows, c, generator=gen) * 0.02).half()
         gs = torch.full([c // 128], 128, dtype=torch.int32)
         gb = torch.full([c // 128], bits, dtype=torch.int32)
-        t0 = time.perf_counter()
-        oracle.gptq_quant(w, hook, gs, gb, use_kernel_semantics=False, block_sizes=gs)
-        t_row[c] = (time.perf_counter() - t0) / rows
-        sample_rows[c] = rows
-        del hook, x, w
+        for r in sorted({r for cc, outs in sets if cc == c for r in outs}):
+            rows = r if r * c <= (1 << 26) else max(256, ((1 << 26) // c) // 256 * 256)
+            w = (torch.randn(rows, c, generator=gen) * 0.02).half()
+            t0 = time.perf_counter()
+            oracle.gptq_quant(w, hook, gs, gb, use_kernel_semantics=False, block_sizes=gs)
+            dt = time.perf_counter() - t0
+            t_layer[(r, c)] = dt * (r / rows)
+            notes.append("gptq_quant %dx%d %.2f s%s" % (r, c, dt, "" if rows == r else " for %d of its rows (scaled by rows)" % rows))
+            del w
+        notes.append("C=%d: add_batch of one 2048-token sequence %.3f s, invert %.2f s" % (c, t_add[c], t_inv[c]))
+        del hook, x
     per_block = 0.0
     for c, outs in sets:
-        per_block += n_seq * t_add[c] + t_inv[c] + sum(outs) * t_row[c]
-    sample = "; ".join("C=%d: add_batch of one 2048-token sequence %.3f s, invert %.2f s, gptq_quant (PyTorch-loop semantics) "
-                       "of %d rows %.2f s" % (c, t_add[c], t_inv[c], sample_rows[c], t_row[c] * sample_rows[c]) for c in widths)
+        per_block += n_seq * t_add[c] + t_inv[c] + sum(t_layer[(r, c)] for r in outs)
     return {"value": round(per_block * n_blocks, 1), "unit": "s", "cores": cores, "kind": "port",
-            "sample": "measured on this host -- " + sample + "; scaled to %d blocks x (4 Hessians of %d sequences, 4 inversions, "
-                      "7 Linears) by sequence and row counts; the replay GEMMs are not part of gptq_py.py and are not in this figure"
-                      % (n_blocks, n_seq)}
+            "sample": "measured on this host (PyTorch-loop semantics) -- " + "; ".join(notes) + "; one block = its 4 Hessians of %d "
+                      "sequences, 4 inversions and 7 Linears at these times, x %d blocks; the replay GEMMs are not part of "
+                      "gptq_py.py and are not in this figure" % (n_seq, n_blocks)}
 
 
 def main():
