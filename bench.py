@@ -166,7 +166,7 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
             with phases["reconstruct"]:
                 dense.append(amd.quant.reconstruct_weight(meta, torch.float16, dev))
             with phases["pack"]:
-                packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True))
+                packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True, dense3=args.bits == 3))
             del meta, res
         del part, by_index
         # replay (llama.py:176-177).  Dense: the Linears of a set read the same input, so up to MERGE_ROWS
@@ -210,9 +210,10 @@ def serving(torch, amd, sets, bits, dev):
                     "perm_inv": torch.argsort(torch.randperm(c, generator=gen, device=dev)).to(torch.int16),
                     "group_sizes": torch.full([c // 128], 128, dtype=torch.int16),
                     "group_bit_widths": torch.full([c // 128], bits, dtype=torch.uint8)}
-            layers.append((c, r, amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True)))
+            layers.append((c, r, amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True, dense3=bits == 3)))
             del meta
-    out = {}
+    out = {"weight_bits_in_memory": 3 if bits == 3 else 4,
+           "packed_weight_bytes_per_block": int(sum(layer.qweight.numel() * 4 for _, _, layer in layers))}
     for batch in (1, 8):
         m = batch * SEQ
         xin = {c: torch.randn(m, c, generator=gen, device=dev).half() for c in {c for c, _, _ in layers}}

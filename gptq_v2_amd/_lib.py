@@ -60,6 +60,9 @@ SIGNATURES = {
                               c_int, c_void_p]),
     "gq_w4a16_gemm_dt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                  c_int, c_int, c_void_p]),
+    "gq_wq_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                           c_int, c_int, c_int, c_void_p]),
+    "gq_set_wq_kernel": (c_int, [c_int]),
     "gq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -8,6 +8,56 @@ namespace {
 // nibble position of value v (0..7) inside a word in the GQ_PACK_W4_PAIRS layout
 __host__ __device__ __forceinline__ int w4_pairs_nibble(int v) { return (v & 1) * 4 + (v >> 1); }
 
+// GQ_PACK_W3_KBLOCK: 32 consecutive levels of a row in 3 words.  Level v < 30 sits in word v / 10 at bit
+// offset 3 * ((v % 10) / 2) of the low (v even) or high (v odd) 16-bit half, so (word >> 3p) & 0x00070007
+// yields the pair (10 j + 2 p, 10 j + 2 p + 1); bit j of level 30 is bit 15 of word j, bit j of level 31
+// is bit 31 of word j.
+__host__ __device__ __forceinline__ uint32_t w3_word(const uint8_t *v32, int j, int64_t n_left)
+{
+    uint32_t word = 0;
+    for (int p = 0; p < 5; ++p) {
+        const int a = 10 * j + 2 * p, b = a + 1;
+        const uint32_t va = a < n_left ? (v32[a] & 7u) : 0u, vb = b < n_left ? (v32[b] & 7u) : 0u;
+        word |= va << (3 * p);
+        word |= vb << (16 + 3 * p);
+    }
+    const uint32_t v30 = 30 < n_left ? (v32[30] & 7u) : 0u, v31 = 31 < n_left ? (v32[31] & 7u) : 0u;
+    word |= ((v30 >> j) & 1u) << 15;
+    word |= ((v31 >> j) & 1u) << 31;
+    return word;
+}
+
+__host__ __device__ __forceinline__ uint32_t w3_level(const uint32_t *w3, int v)
+{
+    if (v < 30) {
+        const int j = v / 10, p = (v % 10) / 2, h = v & 1;
+        return (w3[j] >> (3 * p + 16 * h)) & 7u;
+    }
+    const int sh = v == 30 ? 15 : 31;
+    return ((w3[0] >> sh) & 1u) | (((w3[1] >> sh) & 1u) << 1) | (((w3[2] >> sh) & 1u) << 2);
+}
+
+// one thread per output word of the 3-bit k-block layout: packed[n/64][rows][6]
+__global__ void pack_w3_kernel(const uint8_t *__restrict__ values, int64_t rows, int64_t n, uint32_t *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * (n / 64) * 6) return;
+    const int64_t kb = i / (rows * 6), rem = i - kb * rows * 6;
+    const int64_t row = rem / 6;
+    const int w = (int)(rem - row * 6);           // word of the k-step: chunk w / 3, word w % 3
+    const uint8_t *src = values + row * n + kb * 64 + (w / 3) * 32;
+    packed[i] = w3_word(src, w % 3, 32);
+}
+
+__global__ void unpack_w3_kernel(const uint32_t *__restrict__ packed, int64_t rows, int64_t n, uint8_t *__restrict__ values)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const int64_t row = i / n, idx = i - row * n;
+    const uint32_t *w3 = packed + ((idx >> 6) * rows + row) * 6 + ((idx & 63) >> 5) * 3;
+    values[i] = (uint8_t)w3_level(w3, (int)(idx & 31));
+}
+
 // one thread per output word
 __global__ void pack_kernel(const uint8_t *__restrict__ values, int64_t rows, int64_t n, int bits, int layout,
                             int64_t words_per_row, uint32_t *__restrict__ packed)
@@ -178,10 +228,16 @@ extern "C" int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int 
     GQ_REQUIRE(rows >= 0 && n >= 0, "gq_pack_rows: bad shape");
     GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_pack_rows: bit width %d not in {2,3,4,8}", bits);
     GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4) ||
-                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0),
+                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0) ||
+                   (layout == GQ_PACK_W3_KBLOCK && bits == 3 && n % 64 == 0),
                "gq_pack_rows: bad layout %d for %d bits, n = %lld", layout, bits, (long long)n);
     const int64_t wpr = gq_cdiv(n * bits, 32);
     if (rows * wpr == 0) return GQ_OK;
+    if (layout == GQ_PACK_W3_KBLOCK) {
+        hipLaunchKernelGGL(pack_w3_kernel, dim3((unsigned)gq_cdiv(rows * wpr, 256)), dim3(256), 0, (hipStream_t)stream, values, rows, n, packed);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)gq_cdiv(rows * wpr, 256)), dim3(256), 0, (hipStream_t)stream, values, rows, n, bits, layout, wpr, packed);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
@@ -194,10 +250,16 @@ extern "C" int gq_unpack_rows(const uint32_t *packed, int64_t rows, int64_t n, i
     GQ_REQUIRE(rows >= 0 && n >= 0, "gq_unpack_rows: bad shape");
     GQ_REQUIRE(bits == 2 || bits == 3 || bits == 4 || bits == 8, "gq_unpack_rows: bit width %d not in {2,3,4,8}", bits);
     GQ_REQUIRE(layout == GQ_PACK_STREAM || (layout == GQ_PACK_W4_PAIRS && bits == 4) ||
-                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0),
+                   (layout == GQ_PACK_W4_KBLOCK && bits == 4 && n % 64 == 0) ||
+                   (layout == GQ_PACK_W3_KBLOCK && bits == 3 && n % 64 == 0),
                "gq_unpack_rows: bad layout %d for %d bits, n = %lld", layout, bits, (long long)n);
     const int64_t wpr = gq_cdiv(n * bits, 32);
     if (rows * n == 0) return GQ_OK;
+    if (layout == GQ_PACK_W3_KBLOCK) {
+        hipLaunchKernelGGL(unpack_w3_kernel, dim3((unsigned)gq_cdiv(rows * n, 256)), dim3(256), 0, (hipStream_t)stream, packed, rows, n, values);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    }
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)gq_cdiv(rows * n, 256)), dim3(256), 0, (hipStream_t)stream, packed, rows, n, bits, layout, wpr, values);
     GQ_LAUNCH_CHECK();
     return GQ_OK;

@@ -15,6 +15,8 @@
 
 #include <cstdlib>
 
+#include <atomic>
+
 #include "gq_common.h"
 
 namespace {
@@ -806,6 +808,49 @@ int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const v
 }
 
 }  // namespace
+
+int gq_wq_stream_launch(void *y, const void *x, const uint32_t *qweight_packed, const void *scale, const uint8_t *qzero,
+                        int64_t m, int64_t r, int64_t c, int group_size, int bits, int dtype, hipStream_t stream);
+
+namespace {
+std::atomic<int> g_wq_variant{-1};   // -1: not set yet (GQ_WQ_KERNEL=stream / split decides, else automatic)
+}
+
+extern "C" int gq_set_wq_kernel(int variant)
+{
+    GQ_REQUIRE(variant >= 0 && variant <= 2, "gq_set_wq_kernel: variant must be 0 (automatic), 1 (stream) or 2 (split), got %d", variant);
+    const int before = g_wq_variant.exchange(variant);
+    return before < 0 ? 0 : before;
+}
+
+extern "C" int gq_wq_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale, const uint8_t *qzero,
+                          int64_t m, int64_t r, int64_t c, int group_size, int bits, int dtype, gq_stream_t stream)
+{
+    const char *who = "gq_wq_gemm";
+    GQ_REQUIRE(bits == 3 || bits == 4, "%s: bits must be 3 or 4, got %d", who, bits);
+    int variant = g_wq_variant.load();
+    if (variant < 0) {
+        const char *e = getenv("GQ_WQ_KERNEL");
+        variant = !e ? 0 : (e[0] == 's' && e[1] == 't') ? 1 : 2;
+        int expect = -1;
+        g_wq_variant.compare_exchange_strong(expect, variant);
+    }
+    // 4 bits, measured at M = 16384 on Llama shapes: fp16 -- split 1150-1200 TFLOP/s, stream 980-1130; bf16 (whose
+    // expansion is the longer one) -- split 995-1030, stream 1055-1165, and 761 against 694 at M = 2048 once
+    // there are more tiles than CUs.  So: the split kernel, except bf16 with more than 256 tiles.
+    const bool stream4 = variant == 1 || (variant == 0 && dtype == GQ_BF16 && gq_cdiv(m, W2T) * gq_cdiv(r, W2T) > 256);
+    if (bits == 4 && !stream4) return w4a16_launch(y, x, qweight_packed, scale, qzero, m, r, c, group_size, dtype, stream, who);
+    GQ_REQUIRE(((y && x) || m == 0) && qweight_packed && scale && qzero, "%s: NULL pointer", who);
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: bad dtype %d", who, dtype);
+    GQ_REQUIRE(m >= 0 && r > 0 && c > 0, "%s: bad shape", who);
+    GQ_REQUIRE(c % WK == 0 && c < (1 << 21) && r < (1 << 22), "%s: in_features %lld must be a multiple of %d below 2^21, out_features below 2^22",
+               who, (long long)c, WK);
+    GQ_REQUIRE(group_size >= 32 && group_size % 32 == 0 && c % group_size == 0,
+               "%s: group size %d must be a multiple of 32 dividing in_features", who, group_size);
+    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)qweight_packed | (uintptr_t)y) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    if (m == 0) return GQ_OK;
+    return gq_wq_stream_launch(y, x, qweight_packed, scale, qzero, m, r, c, group_size, bits, dtype, (hipStream_t)stream);
+}
 
 extern "C" int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale,
                              const uint8_t *qzero, int64_t m, int64_t r, int64_t c, int group_size, gq_stream_t stream)

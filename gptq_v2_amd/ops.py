@@ -14,7 +14,7 @@ from . import _lib
 
 GQ_F16, GQ_BF16 = 0, 1
 SEM_KERNEL, SEM_PYTHON = 0, 1
-PACK_STREAM, PACK_W4_PAIRS, PACK_W4_KBLOCK = 0, 1, 2
+PACK_STREAM, PACK_W4_PAIRS, PACK_W4_KBLOCK, PACK_W3_KBLOCK = 0, 1, 2, 3
 
 _DTYPE_CODE = {torch.float16: GQ_F16, torch.bfloat16: GQ_BF16}
 
@@ -257,6 +257,10 @@ def pack_rows(values: torch.Tensor, bits: int, layout: int = PACK_STREAM) -> tor
         if bits != 4 or n % 64:
             raise ValueError("pack_rows: the k-block layout needs 4-bit values and n % 64 == 0")
         out = torch.empty(n // 64, rows, 8, dtype=torch.int32, device=values.device)
+    elif layout == PACK_W3_KBLOCK:
+        if bits != 3 or n % 64:
+            raise ValueError("pack_rows: the 3-bit k-block layout needs 3-bit values and n % 64 == 0")
+        out = torch.empty(n // 64, rows, 6, dtype=torch.int32, device=values.device)
     else:
         out = torch.empty(rows, words_per_row(n, bits), dtype=torch.int32, device=values.device)
     with torch.cuda.device(values.device):
@@ -266,11 +270,12 @@ def pack_rows(values: torch.Tensor, bits: int, layout: int = PACK_STREAM) -> tor
 
 
 def unpack_rows(packed: torch.Tensor, bits: int, n: int, layout: int = PACK_STREAM) -> torch.Tensor:
-    if layout == PACK_W4_KBLOCK:
+    if layout in (PACK_W4_KBLOCK, PACK_W3_KBLOCK):
         _check(packed, "packed", torch.int32, 3)
         rows = packed.shape[1]
-        if bits != 4 or n % 64 or packed.shape[0] != n // 64 or packed.shape[2] != 8:
-            raise ValueError("unpack_rows: k-block layout is (n/64, rows, 8) words of 4-bit values")
+        want_bits, words = (4, 8) if layout == PACK_W4_KBLOCK else (3, 6)
+        if bits != want_bits or n % 64 or packed.shape[0] != n // 64 or packed.shape[2] != words:
+            raise ValueError(f"unpack_rows: k-block layout is (n/64, rows, {words}) words of {want_bits}-bit values")
     else:
         _check(packed, "packed", torch.int32, 2)
         rows = packed.shape[0]
@@ -297,9 +302,10 @@ def permute_columns(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 
 
 def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Tensor, qzero_t: torch.Tensor,
-               group_size: int) -> torch.Tensor:
+               group_size: int, bits: int = 4) -> torch.Tensor:
     """x (M, C) fp16 or bf16, columns in permuted order -> y (M, R) of the same type.
-    qweight_packed (C/64, R, 8) int32 in the k-block layout, scale_t (G, R) of x's type, qzero_t (G, R) uint8."""
+    qweight_packed (C/64, R, 8) int32 in the 4-bit k-block layout, or (C/64, R, 6) in the dense 3-bit one
+    (``bits`` = 3); scale_t (G, R) of x's type, qzero_t (G, R) uint8."""
     _check(x, "x", None, 2)
     code = _dtype_code(x)
     _check(qweight_packed, "qweight_packed", torch.int32, 3)
@@ -308,20 +314,17 @@ def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Ten
     scale, qzero = scale_t, qzero_t
     m, c = x.shape
     r = qweight_packed.shape[1]
-    if (c % 64 or qweight_packed.shape[0] * 64 != c or qweight_packed.shape[2] != 8 or group_size <= 0
+    if bits not in (3, 4):
+        raise ValueError("w4a16_gemm: bits must be 3 or 4")
+    if (c % 64 or qweight_packed.shape[0] * 64 != c or qweight_packed.shape[2] != (8 if bits == 4 else 6) or group_size <= 0
             or c % group_size or scale.shape != (c // group_size, r) or qzero.shape != scale.shape):
         raise ValueError("w4a16_gemm: inconsistent shapes")
     y = torch.empty(m, r, dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        if code == GQ_F16:
-            rc = _lib.load().gq_w4a16_gemm(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c, int(group_size),
-                                           _stream(x))
-        else:
-            rc = _lib.load().gq_w4a16_gemm_dt(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c,
-                                              int(group_size), code, _stream(x))
-    _lib.check(rc, "gq_w4a16_gemm")
+        rc = _lib.load().gq_wq_gemm(_p(y), _p(x), _p(qweight_packed), _p(scale), _p(qzero), m, r, c, int(group_size),
+                                    int(bits), code, _stream(x))
+    _lib.check(rc, "gq_wq_gemm")
     return y
-
 
 def gemm_nt(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """x (M, K) @ weight (N, K)^T -> (M, N), fp16 or bf16, fp32 accumulation: the dense Linear forward

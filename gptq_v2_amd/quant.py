@@ -233,41 +233,74 @@ def reconstruct_nn_linear(quant_meta: dict, dtype: torch.dtype, device: torch.de
 class QuantLinear(nn.Module):
     """Packed int4 Linear: ``pack`` takes a ``quant_meta`` dict, ``forward`` runs the
     W4A16 dequant-GEMM (activations gathered into act-order first when the layer has one).
-    2- and 3-bit layers are held in the same 4-bit containers (the arithmetic (q - z) * scale is
-    the same for every width up to 4), so they cost 4 bits per weight in memory.
+
+    Everything ``reconstruct_nn_linear`` accepts with levels of at most 4 bits can be packed
+    (quant.py:222-279): uniform or mixed group sizes and bit widths, plain or EXL2 scales
+    (``qscale^2 * sscale``, evaluated exactly as the dense reconstruction evaluates them).  Mixed
+    groups are re-expressed on the finest common grid -- groups of gcd(group sizes) columns, each
+    carrying the scale and zero point of the group it lies in -- so the GEMM sees a uniform group
+    size; that gcd must be a multiple of 32.  2- and 3-bit levels sit in the same 4-bit containers
+    (the arithmetic (q - z) * scale is the same for every width up to 4) unless ``dense3`` packing
+    is chosen for a layer whose levels all fit 3 bits.
 
     Packed state, laid out so that a GEMM tile reads contiguous memory: ``qweight`` int32
-    (C/64, R, 8) (pair-interleaved nibbles, k-block major), ``scales`` fp16 or bf16 (G, R), ``qzeros`` uint8
-    (G, R), ``perm`` int32 (C) or None.
-    ``unpack`` returns the original one-value-per-byte ``quant_meta`` tensors bit for bit.
+    (C/64, R, 8) (pair-interleaved nibbles, k-block major; (C/64, R, 6) for ``dense3``),
+    ``scales`` fp16 or bf16 (G', R), ``qzeros`` uint8 (G', R) with G' = C / group_size fine groups,
+    ``perm`` int32 (C) or None.  ``unpack`` returns the original one-value-per-byte ``quant_meta``
+    tensors bit for bit.
     """
 
     def __init__(self, in_features: int, out_features: int, group_size: int = 128, bits: int = 4,
-                 dtype: torch.dtype = torch.float16):
+                 dtype: torch.dtype = torch.float16, group_sizes=None, group_bit_widths=None, dense3: bool = False):
         super().__init__()
         if dtype not in (torch.float16, torch.bfloat16):
             raise NotImplementedError("QuantLinear works in float16 or bfloat16")
         self.dtype = dtype
         if bits not in (2, 3, 4):
             raise NotImplementedError("QuantLinear.forward is implemented for weights of 2 to 4 bits")
+        if dense3 and bits > 3:
+            raise ValueError("dense 3-bit storage needs levels of at most 3 bits")
         self.in_features, self.out_features = in_features, out_features
-        self.group_size, self.bits = group_size, bits
+        self.group_size, self.bits = group_size, bits   # group_size: the GEMM's (fine) group; bits: the widest level
+        self.dense3 = bool(dense3)
+        # the groups as quant_meta describes them (None: in_features / group_size groups of `bits` bits)
+        self.meta_group_sizes = None if group_sizes is None else [int(v) for v in group_sizes]
+        self.meta_group_bits = None if group_bit_widths is None else [int(v) for v in group_bit_widths]
         self.register_buffer("qweight", None)
         self.register_buffer("scales", None)
         self.register_buffer("qzeros", None)
         self.register_buffer("perm", None)
+        self.register_buffer("qscale", None)   # EXL2 metadata, kept only so that unpack() can hand it back
+        self.register_buffer("sscale", None)
+        self.register_buffer("scale_meta", None)   # quant_meta["scale"] of an EXL2 layer (not what the GEMM multiplies by)
 
     @classmethod
-    def from_quant_meta(cls, quant_meta: dict, device, validate: bool = True, has_perm: Optional[bool] = None) -> "QuantLinear":
+    def from_quant_meta(cls, quant_meta: dict, device, validate: bool = True, has_perm: Optional[bool] = None,
+                        dense3: bool = False) -> "QuantLinear":
         r, c = quant_meta["qweight"].shape
         gs = _group_list(quant_meta["group_sizes"])
-        bits = set(_group_list(quant_meta["group_bit_widths"]))
-        if len(set(gs)) != 1 or len(bits) != 1:
-            raise NotImplementedError("QuantLinear needs one group size and one bit width")
+        gb = _group_list(quant_meta["group_bit_widths"])
+        if max(gb) > 4:
+            raise NotImplementedError("QuantLinear holds levels of at most 4 bits")
+        import math
+        fine = 0
+        for v in gs:
+            fine = math.gcd(fine, v)
+        if fine % 32:
+            raise NotImplementedError("QuantLinear needs group sizes with a common divisor that is a multiple of 32")
         sdt = quant_meta["scale"].dtype   # the model's 16-bit type (gptq_py.py:218)
-        layer = cls(c, r, gs[0], bits.pop(), sdt if sdt in (torch.float16, torch.bfloat16) else torch.float16)
+        uniform = len(set(gs)) == 1 and len(set(gb)) == 1
+        layer = cls(c, r, fine, max(2, max(gb)), sdt if sdt in (torch.float16, torch.bfloat16) else torch.float16,
+                    None if uniform else gs, None if uniform else gb, dense3=dense3)
         layer.pack(quant_meta, device, validate=validate, has_perm=has_perm)
         return layer
+
+    def _fine_index(self, device) -> Optional[torch.Tensor]:
+        """For every fine group the index of the quant_meta group it lies in (None: they coincide)."""
+        if self.meta_group_sizes is None:
+            return None
+        reps = torch.tensor([v // self.group_size for v in self.meta_group_sizes], device=device)
+        return torch.repeat_interleave(torch.arange(len(self.meta_group_sizes), device=device), reps)
 
     @torch.no_grad()
     def pack(self, quant_meta: dict, device=None, validate: bool = True, has_perm: Optional[bool] = None) -> None:
@@ -281,13 +314,27 @@ class QuantLinear(nn.Module):
             raise ValueError("quant_meta does not match this layer's shape")
         if self.in_features % 64:
             raise NotImplementedError("QuantLinear needs in_features to be a multiple of 64")
+        qz = quant_meta["qzero"].to(device=device, dtype=torch.uint8)
         if validate:
-            worst = torch.maximum(q.max(), quant_meta["qzero"].to(device=device, dtype=torch.uint8).max())
+            worst = torch.maximum(q.max(), qz.max())
             if int(worst) >= (1 << self.bits):
                 raise ValueError(f"quant_meta holds values outside {self.bits} bits")
-        self.qweight = ops.pack_rows(q, 4, ops.PACK_W4_KBLOCK)
-        self.scales = meta_scale(quant_meta, self.dtype, device).t().contiguous()
-        self.qzeros = quant_meta["qzero"].to(device=device, dtype=torch.uint8).t().contiguous()
+        if self.dense3:
+            self.qweight = ops.pack_rows(q, 3, ops.PACK_W3_KBLOCK)
+        else:
+            self.qweight = ops.pack_rows(q, 4, ops.PACK_W4_KBLOCK)
+        scale = meta_scale(quant_meta, self.dtype, device)
+        idx = self._fine_index(device)
+        if idx is not None:
+            if scale.shape[1] != len(self.meta_group_sizes):
+                raise ValueError("quant_meta's scale does not match its group_sizes")
+            scale, qz = scale[:, idx], qz.expand(scale.shape)[:, idx]
+        self.scales = scale.t().contiguous()
+        self.qzeros = qz.expand(self.out_features, self.scales.shape[0]).t().contiguous()
+        if quant_meta.get("sscale") is not None:
+            self.qscale = quant_meta["qscale"].to(device)
+            self.sscale = quant_meta["sscale"].to(device)
+            self.scale_meta = quant_meta["scale"].to(device)
         perm_inv = quant_meta.get("perm_inv")
         if perm_inv is None or has_perm is False:
             self.perm = None
@@ -304,7 +351,10 @@ class QuantLinear(nn.Module):
 
     @torch.no_grad()
     def unpack(self) -> dict:
-        q = ops.unpack_rows(self.qweight, 4, self.in_features, ops.PACK_W4_KBLOCK)
+        if self.dense3:
+            q = ops.unpack_rows(self.qweight, 3, self.in_features, ops.PACK_W3_KBLOCK)
+        else:
+            q = ops.unpack_rows(self.qweight, 4, self.in_features, ops.PACK_W4_KBLOCK)
         c = self.in_features
         if self.perm is None:
             perm_inv = torch.arange(c, dtype=torch.int16, device=q.device)
@@ -312,12 +362,25 @@ class QuantLinear(nn.Module):
             perm_inv = torch.empty(c, dtype=torch.int64, device=q.device)
             perm_inv[self.perm.long()] = torch.arange(c, device=q.device)
             perm_inv = perm_inv.to(torch.int16)
-        g = c // self.group_size
-        return {"qweight": q, "scale": self.scales.t().contiguous(), "qzero": self.qzeros.t().contiguous(),
-                "qscale": None, "sscale": None,
+        scale, qzero = self.scales.t(), self.qzeros.t()
+        if self.meta_group_sizes is None:
+            gs = [self.group_size] * (c // self.group_size)
+            gb = [self.bits] * len(gs)
+        else:
+            gs, gb = self.meta_group_sizes, self.meta_group_bits
+            first, at = [], 0
+            for v in gs:   # the first fine group of every quant_meta group
+                first.append(at)
+                at += v // self.group_size
+            first = torch.tensor(first, device=q.device)
+            scale, qzero = scale[:, first], qzero[:, first]
+        if self.scale_meta is not None:
+            scale = self.scale_meta
+        return {"qweight": q, "scale": scale.contiguous(), "qzero": qzero.contiguous(),
+                "qscale": self.qscale, "sscale": self.sscale,
                 "perm_inv": perm_inv,
-                "group_sizes": torch.full([g], self.group_size, dtype=torch.int16, device=q.device),
-                "group_bit_widths": torch.full([g], self.bits, dtype=torch.uint8, device=q.device),
+                "group_sizes": torch.tensor(gs, dtype=torch.int16, device=q.device),
+                "group_bit_widths": torch.tensor(gb, dtype=torch.uint8, device=q.device),
                 "scale_bit_width": None}
 
     @torch.no_grad()
@@ -339,7 +402,7 @@ class QuantLinear(nn.Module):
         x2 = x_permuted.reshape(-1, shape[-1])
         if x2.dtype != self.dtype:
             raise NotImplementedError(f"this QuantLinear takes {self.dtype} activations, got {x2.dtype}")
-        y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size)
+        y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size, bits=3 if self.dense3 else 4)
         return y.reshape(*shape[:-1], self.out_features)
 
     @torch.no_grad()

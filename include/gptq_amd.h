@@ -212,6 +212,12 @@ int gq_dequantize(const uint8_t *qweight, const void *scale, const uint8_t *qzer
                                  contiguous bytes and consecutive rows follow each other, so a GEMM
                                  tile reads one contiguous piece per k-step: the W4A16 GEMM operand */
 
+#define GQ_PACK_W3_KBLOCK 3   /* 3-bit only, n a multiple of 64: packed[n/64][rows][6]; each run of 32 values
+                                 is 3 words -- value v < 30 in word v / 10 at bit offset 3 * ((v % 10) / 2) of the
+                                 low (v even) or high (v odd) half, so (w >> 3p) & 0x00070007 yields a value pair;
+                                 bit j of values 30 / 31 is bit 15 / 31 of word j: 3 bits per weight in memory,
+                                 the operand of gq_wq_gemm with bits = 3 */
+
 /* Packing of rows of `bits`-wide values (2, 3, 4 or 8) into uint32 words,
  * words_per_row = ceil(n*bits/32), rows padded with zero bits.
  * No reference counterpart (the reference stores one value per byte, gptq_py.py:217). */
@@ -241,6 +247,22 @@ int gq_w4a16_gemm(void *y, const void *x, const uint32_t *qweight_packed, const 
 int gq_w4a16_gemm_dt(void *y, const void *x, const uint32_t *qweight_packed, const void *scale_t,
                      const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size,
                      int dtype, gq_stream_t stream);
+
+/* The packed product for 4-bit (GQ_PACK_W4_KBLOCK) or dense 3-bit (GQ_PACK_W3_KBLOCK) weights: same
+ * arguments and arithmetic as gq_w4a16_gemm_dt, `bits` = 4 or 3 names the operand layout.  Group sizes
+ * are multiples of 32 dividing C (a layer with mixed groups is passed on the grid of their common
+ * divisor, every fine group carrying the scale and zero point of the group it lies in).
+ * Fills the slot of llama.py:172-177 like gq_w4a16_gemm; the reference has no packed storage. */
+int gq_wq_gemm(void *y, const void *x, const uint32_t *qweight_packed, const void *scale_t,
+               const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size, int bits, int dtype,
+               gq_stream_t stream);
+
+/* Which kernel gq_wq_gemm runs for 4-bit operands: 0 = chosen by shape (the default), 1 = the stream
+ * kernel (one barrier per k-step, expansion between the matrix instructions), 2 = the split kernel
+ * (expansion and matrix waves apart; the one gq_w4a16_gemm runs).  Returns the previous setting, -1 on a
+ * bad argument.  Dense 3-bit operands always take the stream kernel.  A tuning knob of this library, no
+ * reference counterpart; the environment variable GQ_WQ_KERNEL=stream|split sets the initial value. */
+int gq_set_wq_kernel(int variant);
 
 /* y[M][N] = x[M][K] * w[N][K]^T for dense 16-bit operands (dtype GQ_F16 or GQ_BF16 for all three),
  * fp32 accumulation, one rounding of the result: the forward of the dense nn.Linear that the

@@ -442,6 +442,28 @@ def unpack_rows(packed: torch.Tensor, bits: int, n: int) -> torch.Tensor:
     return torch.from_numpy(out)
 
 
+def pack_rows_w3_kblock(values: torch.Tensor) -> torch.Tensor:
+    """The GEMM operand layout of dense 3-bit levels (defined here, no reference counterpart):
+    (rows, n) -> (n/64, rows, 6) words.  Every run of 32 levels of a row takes 3 words: level v < 30
+    sits in word v // 10 at bit offset 3 * ((v % 10) // 2), in the low 16-bit half if v is even and
+    the high half if odd; bit j of level 30 is bit 15 of word j, bit j of level 31 is bit 31."""
+    v = values.to(torch.int64).numpy()
+    rows, n = v.shape
+    assert n % 64 == 0 and v.min(initial=0) >= 0 and v.max(initial=0) < 8
+    out = np.zeros((n // 64, rows, 6), dtype=np.uint64)
+    for i in range(n):
+        kb, chunk, lv = i // 64, (i % 64) // 32, i % 32
+        col = v[:, i].astype(np.uint64)
+        if lv < 30:
+            word, sh = lv // 10, 3 * ((lv % 10) // 2) + 16 * (lv & 1)
+            out[kb, :, chunk * 3 + word] |= col << np.uint64(sh)
+        else:
+            sh = 15 if lv == 30 else 31
+            for j in range(3):
+                out[kb, :, chunk * 3 + j] |= ((col >> np.uint64(j)) & np.uint64(1)) << np.uint64(sh)
+    return torch.from_numpy(out.astype(np.uint32).view(np.int32))
+
+
 def w4a16_linear(x: torch.Tensor, meta: dict) -> torch.Tensor:
     """What QuantLinear.forward must approximate: the reference's reconstruct-then-dense
     path (llama.py:172-177) with the fp16 weight and an exact (fp64) contraction."""
