@@ -73,8 +73,13 @@ class HessianHook:
 # and fill each other's gaps (measured on the Llama-2-7B block: 32.6 -> 27.4 ms).  Slicing the
 # rows of ONE Linear over streams does not pay: a slice's chain is barely shorter than the whole
 # layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1.
-# HIP gives a process 4 hardware queues by default: more streams would only be serialised again.
-N_QUANT_STREAMS = 4
+# HIP gives a process 4 hardware queues by default and streams beyond that share a queue, where a
+# wait of one stream holds up the kernels of the other behind it: three side streams plus the
+# caller's stream stay within the four (no set of a Llama block has more than three Linears).
+# The graph is a plain fork / join -- every side stream waits for the caller's stream once, the
+# caller's stream waits for every side stream once, no side stream waits for another, no event is
+# recorded twice, no stream has a priority -- so it has no cycle whatever the queue mapping is.
+N_QUANT_STREAMS = 3
 ROW_SLICES = 1
 MIN_SLICE_ROWS = 256
 _streams: dict = {}
