@@ -28,7 +28,8 @@
 // arithmetic for the fragment reads 1-3 %; a four-barrier read / MFMA role split of the two waves
 // of a SIMD was 4-8 % slower, a persistent grid that pipelines across tile boundaries 5 % slower
 // (the idle time between tiles costs no energy), four waves of 128 x 128 (a third fewer LDS bytes
-// per flop, one wave per SIMD) 3 % slower.
+// per flop, one wave per SIMD) 3 % slower, non-temporal stores of y 3-7 % slower and non-temporal loads of
+// either operand 10-18 % slower (the re-reads of x and w are served by the caches the hint bypasses).
 #include <algorithm>
 #include <type_traits>
 

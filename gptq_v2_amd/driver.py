@@ -351,3 +351,24 @@ def load_results_into(model: nn.Module, results_or_path, device: torch.device, p
         else:
             getattr(parent, leaf).weight.data = reconstruct_weight(meta, dtype, device)
     return model
+
+
+def save_packed(model: nn.Module, path: str) -> None:
+    """The packed variant of the on-disk format: ``{'packed': {module name: QuantLinear.packed_state()}}``
+    for every ``QuantLinear`` of ``model`` -- 4 (or 3) bits per weight on disk instead of the
+    reference's one byte per level (gptq_py.py:217); loads with ``torch.load(weights_only=True)``."""
+    packed = {name: m.packed_state() for name, m in model.named_modules() if isinstance(m, QuantLinear)}
+    if not packed:
+        raise ValueError("save_packed: the model has no QuantLinear layers")
+    torch.save({"packed": packed}, path)
+
+
+@torch.no_grad()
+def load_packed_into(model: nn.Module, path: str, device: torch.device) -> nn.Module:
+    """Replaces the named Linears of ``model`` by the ``QuantLinear`` layers of a ``save_packed`` file;
+    nothing is re-packed, the words go to the device as they are."""
+    res = torch.load(path, weights_only=True)
+    for name, state in res["packed"].items():
+        parent_name, leaf = name.rsplit(".", 1)
+        setattr(model.get_submodule(parent_name), leaf, QuantLinear.from_packed_state(state, device))
+    return model

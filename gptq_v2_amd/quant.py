@@ -383,6 +383,36 @@ class QuantLinear(nn.Module):
                 "group_bit_widths": torch.tensor(gb, dtype=torch.uint8, device=q.device),
                 "scale_bit_width": None}
 
+    def packed_state(self) -> dict:
+        """The layer as tensors, numbers, lists and None only (a file of these loads with
+        ``torch.load(weights_only=True)``): the packed words as they lie in memory -- 4 or 3 bits per
+        weight -- instead of the one byte per level of ``quant_meta``."""
+        return {"in_features": self.in_features, "out_features": self.out_features, "group_size": self.group_size,
+                "bits": self.bits, "dense3": self.dense3, "dtype": "float16" if self.dtype == torch.float16 else "bfloat16",
+                "group_sizes": self.meta_group_sizes, "group_bit_widths": self.meta_group_bits,
+                "qweight": self.qweight, "scales": self.scales, "qzeros": self.qzeros, "perm": self.perm,
+                "qscale": self.qscale, "sscale": self.sscale, "scale_meta": self.scale_meta}
+
+    @classmethod
+    def from_packed_state(cls, state: dict, device) -> "QuantLinear":
+        layer = cls(int(state["in_features"]), int(state["out_features"]), int(state["group_size"]), int(state["bits"]),
+                    torch.float16 if state["dtype"] == "float16" else torch.bfloat16, state["group_sizes"],
+                    state["group_bit_widths"], dense3=bool(state["dense3"]))
+        words = 6 if layer.dense3 else 8
+        g = layer.in_features // layer.group_size
+        want = {"qweight": ((layer.in_features // 64, layer.out_features, words), torch.int32),
+                "scales": ((g, layer.out_features), layer.dtype), "qzeros": ((g, layer.out_features), torch.uint8)}
+        for name, (shape, dt) in want.items():
+            t = state[name]
+            if tuple(t.shape) != shape or t.dtype != dt:
+                raise ValueError(f"packed state: {name} is {tuple(t.shape)} {t.dtype}, expected {shape} {dt}")
+        if state["perm"] is not None and (state["perm"].dtype != torch.int32 or state["perm"].numel() != layer.in_features):
+            raise ValueError("packed state: perm must be int32 of in_features entries")
+        for name in ("qweight", "scales", "qzeros", "perm", "qscale", "sscale", "scale_meta"):
+            t = state[name]
+            setattr(layer, name, None if t is None else t.to(device).contiguous())
+        return layer
+
     @torch.no_grad()
     def permute_input(self, x: torch.Tensor) -> torch.Tensor:
         """x[..., perm]: the activation gather of act-order.  Layers quantised against the same

@@ -126,6 +126,26 @@ def test_results_round_trip_through_the_reference_file_format(amd, gpu, tmp_path
     p_dense = float(driver.evaluate_llama(dense, enc, gpu, batch_size=4))
     p_packed = float(driver.evaluate_llama(packed, enc, gpu, batch_size=4))
     assert abs(p_dense - p_packed) / p_dense < 0.02
+    # the packed file: the words as they lie in device memory, nothing re-packed on load
+    ppath = str(tmp_path / "packed.pth")
+    driver.save_packed(packed, ppath)
+    again = driver.load_packed_into(copy.deepcopy(model), ppath, gpu)
+    n_layers = 0
+    for (n1, m1), (n2, m2) in zip(packed.named_modules(), again.named_modules()):
+        if isinstance(m1, amd.QuantLinear):
+            assert isinstance(m2, amd.QuantLinear) and n1 == n2
+            for k in ("qweight", "scales", "qzeros", "perm"):
+                a, b = getattr(m1, k), getattr(m2, k)
+                assert (a is None and b is None) or torch.equal(a, b), (n1, k)
+            back = m2.unpack()
+            assert torch.equal(back["qweight"].cpu(), res["data"][n1]["qweight"].cpu()), n1
+            n_layers += 1
+    assert n_layers == 7 * len(model.model.layers)
+    assert float(driver.evaluate_llama(again, enc, gpu, batch_size=4)) == p_packed
+    import os
+    assert os.path.getsize(ppath) < 0.75 * os.path.getsize(path)   # 4 bits per level against 8 (plus scales either way)
+    with pytest.raises(ValueError):
+        driver.save_packed(model, ppath)
 
 
 @pytest.mark.parametrize("pack", [False, True])
