@@ -63,6 +63,9 @@ SIGNATURES = {
     "gq_wq_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                            c_int, c_int, c_int, c_void_p]),
     "gq_set_wq_kernel": (c_int, [c_int]),
+    "gq_xtx_split_hint": (c_int, [c_int64, c_int64, c_int]),
+    "gq_xtx_accumulate_split": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "gq_xtx_fold": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "gq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -348,8 +348,8 @@ __device__ unsigned long long *g_xtx_trace = nullptr;
 
 template <int DTYPE>
 __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
-                                                     int hidden, int n_ktiles, const uint32_t *__restrict__ tile_table,
-                                                     int n_blocks, int mirror)
+                                                     int hidden, int n_ktiles_all, const uint32_t *__restrict__ tile_table,
+                                                     int n_blocks, int mirror, int n_tiles, int n_splits, int64_t part_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef GQ_XTX_TRACE
@@ -367,10 +367,18 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
         const int q = n_blocks >> 3, r = n_blocks & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const uint32_t packed_tile = tile_table[bid];
+    // token split: workgroup (tile, split) adds the products of its share of the k-steps into partial
+    // Hessian `split` (part_stride floats apart); the caller sums the parts
+    const int split = bid / n_tiles;
+    const uint32_t packed_tile = tile_table[bid - split * n_tiles];
     const int ti = (int)(packed_tile >> 16), tj = (int)(packed_tile & 0xffffu);
     const int m0 = ti * T2, n0 = tj * T2;
     const int64_t ld = hidden;
+    const int k_begin = (int)((int64_t)n_ktiles_all * split / n_splits);
+    const int n_ktiles = (int)((int64_t)n_ktiles_all * (split + 1) / n_splits) - k_begin;
+    if (n_ktiles == 0) return;   // uniform over the workgroup
+    x += (int64_t)k_begin * BK2 * ld;
+    hess += (int64_t)split * part_stride;
 
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
@@ -634,7 +642,7 @@ int launch_mfma(float *hess, const unsigned short *x, int64_t n_tokens, int64_t 
 
 template <int DTYPE>
 int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64_t hidden, int compute_lower_only,
-                   int mirror, hipStream_t stream, int64_t &done)
+                   int mirror, hipStream_t stream, int64_t &done, int n_splits = 1, int64_t part_stride = 0)
 {
     const int nt = (int)(hidden / T2);
     const int n_ktiles = (int)(n_tokens / BK2);
@@ -645,8 +653,8 @@ int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64
     int rc = get_tile_table(nt, compute_lower_only, 6, &table, &n_blocks);
     if (rc) return rc;
     GQ_HIP(hipFuncSetAttribute((const void *)xtx256_kernel<DTYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
-    hipLaunchKernelGGL(xtx256_kernel<DTYPE>, dim3(n_blocks), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles,
-                       table, n_blocks, mirror);
+    hipLaunchKernelGGL(xtx256_kernel<DTYPE>, dim3(n_blocks * n_splits), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden,
+                       n_ktiles, table, n_blocks * n_splits, mirror, n_blocks, n_splits, part_stride);
     GQ_LAUNCH_CHECK();
     done = (int64_t)n_ktiles * BK2;
     return GQ_OK;
@@ -733,4 +741,105 @@ extern "C" int gq_xtx_accumulate(float *hessian, const void *x, int dtype, int64
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GQ_F16) return launch_xtx<GQ_F16>(hessian, (const unsigned short *)x, n_tokens, hidden, save_lower_only, compute_lower_only, s);
     return launch_xtx<GQ_BF16>(hessian, (const unsigned short *)x, n_tokens, hidden, save_lower_only, compute_lower_only, s);
+}
+
+// ---- token split over partial Hessians ---------------------------------------------------------
+// With few output tiles (C = 4096: 136 lower tiles of 256 x 256 on 256 CUs) one workgroup per tile
+// leaves CUs idle.  The tokens of a call are then cut into n_parts runs and workgroup (tile, run)
+// adds its products into partial Hessian `run`; the parts are summed in index order when H is
+// needed (gq_xtx_fold), so the result does not depend on the order in which workgroups finish and
+// stays exactly symmetric (every part is, and the sums of mirrored elements add the same numbers in
+// the same order).
+
+extern "C" int gq_xtx_split_hint(int64_t hidden, int64_t n_tokens, int compute_lower_only)
+{
+    if (hidden <= 0 || hidden % T2 || n_tokens < 64 * BK2) return 1;
+    const int64_t nt = hidden / T2, tiles = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
+    // time in units of one full-token tile per CU: rounds of workgroups over 256 CUs, each 1 / parts long,
+    // plus the read-modify-write of one more partial Hessian per extra part (about 5 % of a tile's time at
+    // 32768 tokens per call, proportionally more for shorter calls)
+    const double rmw = 0.05 * 32768.0 / (double)n_tokens * std::min(1.0, (double)tiles / 256.0);
+    int best = 1;
+    double best_cost = (double)gq_cdiv(tiles, 256);
+    for (int parts = 2; parts <= 4; ++parts) {
+        if (n_tokens / BK2 < 64 * parts) break;
+        const double cost = (double)gq_cdiv(tiles * parts, 256) / parts + rmw * (parts - 1);
+        if (cost < 0.9 * best_cost) {
+            best = parts;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+extern "C" int gq_xtx_accumulate_split(float *parts, int n_parts, int64_t part_stride, const void *x, int dtype,
+                                       int64_t n_tokens, int64_t hidden, int save_lower_only, int compute_lower_only,
+                                       gq_stream_t stream)
+{
+    const char *who = "gq_xtx_accumulate_split";
+    GQ_REQUIRE(parts && (x || n_tokens == 0), "%s: NULL pointer", who);
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: dtype %d is neither fp16 (0) nor bf16 (1)", who, dtype);
+    GQ_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden < (1 << 30), "%s: bad shape tokens=%lld hidden=%lld", who,
+               (long long)n_tokens, (long long)hidden);
+    GQ_REQUIRE(n_parts >= 1 && n_parts <= 16, "%s: n_parts must be 1..16, got %d", who, n_parts);
+    GQ_REQUIRE(n_parts == 1 || (part_stride >= hidden * hidden && part_stride % 4 == 0),
+               "%s: part_stride %lld must be a multiple of 4 floats and hold a %lld x %lld matrix", who, (long long)part_stride,
+               (long long)hidden, (long long)hidden);
+    GQ_REQUIRE(compute_lower_only || !save_lower_only, "compute_lower_only must be set when save_lower_only is set");
+    GQ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)parts & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    if (n_tokens == 0) return GQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_ktiles = n_tokens / BK2;
+    if (n_parts == 1 || hidden % T2 || n_ktiles < n_parts) {   // nothing to split: everything into part 0
+        if (dtype == GQ_F16) return launch_xtx<GQ_F16>(parts, (const unsigned short *)x, n_tokens, hidden, save_lower_only, compute_lower_only, s);
+        return launch_xtx<GQ_BF16>(parts, (const unsigned short *)x, n_tokens, hidden, save_lower_only, compute_lower_only, s);
+    }
+    const int mirror = compute_lower_only && !save_lower_only;
+    int64_t done = 0;
+    int rc = dtype == GQ_F16
+                 ? launch_mfma256<GQ_F16>(parts, (const unsigned short *)x, n_tokens, hidden, compute_lower_only, mirror, s, done, n_parts, part_stride)
+                 : launch_mfma256<GQ_BF16>(parts, (const unsigned short *)x, n_tokens, hidden, compute_lower_only, mirror, s, done, n_parts, part_stride);
+    if (rc) return rc;
+    if (done < n_tokens) {   // the tokens that do not fill a k-step: generic kernel, into part 0
+        const int nt = (int)gq_cdiv(hidden, 64);
+        const int n_blocks = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
+        if (dtype == GQ_F16)
+            hipLaunchKernelGGL(xtx_generic_kernel<GQ_F16>, dim3(n_blocks), dim3(256), 0, s, parts, (const unsigned short *)x, (int)hidden, done,
+                               n_tokens, nt, compute_lower_only, mirror);
+        else
+            hipLaunchKernelGGL(xtx_generic_kernel<GQ_BF16>, dim3(n_blocks), dim3(256), 0, s, parts, (const unsigned short *)x, (int)hidden, done,
+                               n_tokens, nt, compute_lower_only, mirror);
+        GQ_LAUNCH_CHECK();
+    }
+    return GQ_OK;
+}
+
+namespace {
+// parts[0][i] += parts[1][i] + ... (in index order); parts[1..] = 0
+__global__ void xtx_fold_kernel(float *__restrict__ parts, int n_parts, int64_t part_stride, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 *p0 = reinterpret_cast<f32x4 *>(parts) + i;
+        f32x4 acc = *p0;
+        for (int p = 1; p < n_parts; ++p) {
+            f32x4 *pp = reinterpret_cast<f32x4 *>(parts + (int64_t)p * part_stride) + i;
+            acc += *pp;
+            *pp = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *p0 = acc;
+    }
+}
+}  // namespace
+
+extern "C" int gq_xtx_fold(float *parts, int n_parts, int64_t part_stride, int64_t hidden, gq_stream_t stream)
+{
+    GQ_REQUIRE(parts && n_parts >= 1 && n_parts <= 16 && hidden > 0, "gq_xtx_fold: bad arguments");
+    GQ_REQUIRE(n_parts == 1 || (part_stride >= hidden * hidden && part_stride % 4 == 0), "gq_xtx_fold: bad part_stride");
+    GQ_REQUIRE(((uintptr_t)parts & 15) == 0 && (hidden * hidden) % 4 == 0, "gq_xtx_fold: 16-byte alignment");
+    if (n_parts == 1) return GQ_OK;
+    const int64_t n4 = hidden * hidden / 4;
+    hipLaunchKernelGGL(xtx_fold_kernel, dim3((unsigned)std::min<int64_t>(gq_cdiv(n4, 256), 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       parts, n_parts, part_stride, n4);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
 }

@@ -22,12 +22,30 @@ class HessianHook:
     (gptq_py.py:9-66)."""
 
     def __init__(self) -> None:
-        self.hessian: Optional[torch.Tensor] = None
+        self._hessian: Optional[torch.Tensor] = None
+        # With few output tiles (C = 4096) the tokens of a batch are cut into runs that accumulate into
+        # partial Hessians (ops.xtx_accumulate_split); `_hessian` is then parts[0] and reading `hessian`
+        # first adds the other parts into it.
+        self._parts: Optional[torch.Tensor] = None
+        self._parts_dirty = False
         self.n_samples: int = 0
         self.hessian_inv: Optional[torch.Tensor] = None
         self.perm: Optional[torch.Tensor] = None
         self.perm_inv: Optional[torch.Tensor] = None
         self.tries: int = 0
+
+    @property
+    def hessian(self) -> Optional[torch.Tensor]:
+        if self._parts_dirty:
+            ops.xtx_fold(self._parts)
+            self._parts_dirty = False
+        return self._hessian
+
+    @hessian.setter
+    def hessian(self, value: Optional[torch.Tensor]) -> None:
+        self._hessian = value
+        self._parts = None
+        self._parts_dirty = False
 
     @torch.no_grad()
     def add_batch(self, inp: torch.Tensor, use_kernel: bool = True) -> None:
@@ -43,15 +61,24 @@ class HessianHook:
             inp = inp[None]
         self.n_samples += len(inp)
         d = inp.size(-1)
-        if self.hessian is None:
-            self.hessian = torch.zeros(d, d, dtype=torch.float32, device=inp.device)
         x = inp.flatten(end_dim=-2)
+        if self._hessian is None:
+            n_parts = ops.xtx_split_hint(d, x.shape[0]) if use_kernel and inp.is_cuda else 1
+            if n_parts > 1:
+                self._parts = torch.zeros(n_parts, d, d, dtype=torch.float32, device=inp.device)
+                self._hessian = self._parts[0]
+            else:
+                self._hessian = torch.zeros(d, d, dtype=torch.float32, device=inp.device)
         if not use_kernel:
             ops.xtx_accumulate_f32(self.hessian, x.to(dtype=torch.float32).contiguous())
             return
         if not x.is_contiguous():
             x = x.contiguous()
-        ops.xtx_accumulate(self.hessian, x, save_lower_only=False, compute_lower_only=True)
+        if self._parts is not None:
+            ops.xtx_accumulate_split(self._parts, x, save_lower_only=False, compute_lower_only=True)
+            self._parts_dirty = True
+        else:
+            ops.xtx_accumulate(self._hessian, x, save_lower_only=False, compute_lower_only=True)
 
     @torch.no_grad()
     def invert(self, damp_ratio: float = 1e-2, act_order: bool = True) -> torch.Tensor:

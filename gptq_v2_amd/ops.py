@@ -68,6 +68,37 @@ def xtx_accumulate(hessian: torch.Tensor, x: torch.Tensor, save_lower_only: bool
     _lib.check(rc, "gq_xtx_accumulate")
 
 
+def xtx_split_hint(hidden: int, n_tokens: int, compute_lower_only: bool = True) -> int:
+    """Number of partial Hessians that pays for calls of ``n_tokens`` tokens (1: do not split)."""
+    return int(_lib.load().gq_xtx_split_hint(int(hidden), int(n_tokens), int(compute_lower_only)))
+
+
+def xtx_accumulate_split(parts: torch.Tensor, x: torch.Tensor, save_lower_only: bool = False,
+                         compute_lower_only: bool = True) -> None:
+    """parts (S, C, C) fp32: the tokens of x (N, C) fp16/bf16 are cut into S runs, run p adds its X^T X
+    into parts[p].  The Hessian is parts.sum(0), which ``xtx_fold`` leaves in parts[0]."""
+    _check(parts, "parts", torch.float32, 3)
+    _check(x, "x", None, 2)
+    code = _dtype_code(x)
+    n, c = x.shape
+    if parts.shape[1:] != (c, c):
+        raise ValueError(f"parts is {tuple(parts.shape)}, x has {c} columns")
+    if x.device != parts.device:
+        raise ValueError("parts and x are on different devices")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_xtx_accumulate_split(_p(parts), parts.shape[0], c * c, _p(x), code, n, c, int(save_lower_only),
+                                                 int(compute_lower_only), _stream(x))
+    _lib.check(rc, "gq_xtx_accumulate_split")
+
+
+def xtx_fold(parts: torch.Tensor) -> None:
+    """parts[0] += parts[1] + parts[2] + ... (in this order), parts[1:] = 0."""
+    _check(parts, "parts", torch.float32, 3)
+    with torch.cuda.device(parts.device):
+        rc = _lib.load().gq_xtx_fold(_p(parts), parts.shape[0], parts.shape[1] * parts.shape[2], parts.shape[1], _stream(parts))
+    _lib.check(rc, "gq_xtx_fold")
+
+
 def xtx_accumulate_f32(hessian: torch.Tensor, x: torch.Tensor) -> None:
     """hessian (C, C) fp32 += x^T x for x (N, C) fp32 (the reference's add_batch(use_kernel=False)
     arithmetic, gptq_py.py:31-33).  N is padded to a multiple of 4 with zero rows."""

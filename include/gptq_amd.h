@@ -58,6 +58,19 @@ int gq_version(void);
 int gq_xtx_accumulate(float *hessian, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
                       int save_lower_only, int compute_lower_only, gq_stream_t stream);
 
+/* The same accumulation with the tokens of the call cut into n_parts runs, run p added into the
+ * partial Hessian parts + p * part_stride (floats; part_stride >= hidden^2, a multiple of 4): with few
+ * output tiles (hidden = 4096: 136 lower tiles on 256 CUs) one workgroup per tile leaves CUs idle,
+ * (tile, run) workgroups fill them.  H is the sum of the parts; gq_xtx_fold adds parts 1.. into part 0
+ * in index order and clears them, so H does not depend on the order in which workgroups finished and is
+ * exactly symmetric.  Shapes the split does not apply to go into part 0 whole.  gq_xtx_split_hint
+ * returns the number of parts that pays for a call of n_tokens (1 = do not split).
+ * ref: gptq_triton/accumulate_hessian.py:134-149 (same contract per part). */
+int gq_xtx_split_hint(int64_t hidden, int64_t n_tokens, int compute_lower_only);
+int gq_xtx_accumulate_split(float *parts, int n_parts, int64_t part_stride, const void *x, int dtype, int64_t n_tokens,
+                            int64_t hidden, int save_lower_only, int compute_lower_only, gq_stream_t stream);
+int gq_xtx_fold(float *parts, int n_parts, int64_t part_stride, int64_t hidden, gq_stream_t stream);
+
 /* The same accumulation for fp32 activations X[n_tokens][hidden]: full product on the fp32 matrix
  * core, every element one k-ascending chain of fused multiply-adds (exactly symmetric result).
  * n_tokens and hidden must be multiples of 4 (zero rows may be appended to X).
