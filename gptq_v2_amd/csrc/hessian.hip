@@ -475,6 +475,97 @@ int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *st
     return gq_sgemm(g, stream);
 }
 
+// The same (L, L^-1) with the triangular inverse taken off the factorisation's chain.
+//
+// Factorisation, right-looking over 128-column panels: leaf (L_jj^-1 of the diagonal block), panel
+// L21 = B * L_jj^-T, trailing update D -= L21 L21^T -- applied at once only to the columns of the
+// current super-panel of four panels, and to everything beyond it once per super-panel with the four
+// panels together (a 512-deep product runs at three times the rate of four 128-deep ones).  The panel
+// and update GEMMs span the whole remaining height, so they fill the chip where the recursion's small
+// nodes do not.  Afterwards linv holds the L_jj^-1 on its diagonal blocks and the raw entries of L
+// below them.
+//
+// Inverse, by doubling: inv([L11 0; L21 L22]) = [L11^-1 0; -L22^-1 (L21 L11^-1) L22^-1].  The nodes of
+// one level are independent and, for the aligned nodes of 2^l blocks, equally shaped and equally
+// spaced: floor(nb / 2^l) of them go into ONE batched launch per product (two per level).  A block
+// count that is not a power of two leaves a chain of complete subtrees of decreasing size (the bits
+// of nb, left to right); they are joined right to left at the end, one unbatched pair of products
+// each.  X = L21 L11^-1 goes into w (its lower part is free once the factorisation is done).
+int cholinv_panels(float *w, float *linv, int64_t ld, int64_t n, int *status, hipStream_t stream)
+{
+    const int nb = (int)(n / NB);
+    int rc;
+    GqSgemmArgs g{};
+    g.lda = g.ldb = g.ldc = ld;
+    static const int SP = [] {   // panels per super-panel: updates beyond it wait and are applied SP * 128 deep
+        const char *e = getenv("GQ_INVERT_SP");
+        return e && atoi(e) > 0 ? atoi(e) : 4;
+    }();
+    for (int j = 0; j < nb; ++j) {
+        const int64_t o = (int64_t)j * NB, rest = n - o - NB;
+        hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(256), LEAF_LDS, stream, w, linv, ld, o, status);
+        GQ_LAUNCH_CHECK();
+        if (rest == 0) break;
+        const int sp_end = std::min(nb, (j / SP + 1) * SP);   // first panel of the next super-panel
+        float *b21 = w + (o + NB) * ld + o;          // B
+        float *ijj = linv + o * ld + o;              // L_jj^-1
+        float *l21 = linv + (o + NB) * ld + o;       // L21 (stays: the inverse pass reads it)
+        g.batch = 0;
+        g.a = b21; g.b = ijj; g.c = l21; g.m = (int)rest; g.n = NB; g.k = NB;
+        g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_K_LE_N; g.negate = 0; g.accumulate = 0; g.lower_only = 0;
+        if ((rc = gq_sgemm(g, stream))) return rc;
+        // now: the columns of this super-panel that are still to come, all rows below (the tiles above the
+        // diagonal of that strip are computed too; nobody reads them)
+        const int64_t near_cols = (int64_t)(sp_end - (j + 1)) * NB;
+        if (near_cols > 0) {
+            g.a = l21; g.b = l21; g.c = w + (o + NB) * ld + o + NB; g.m = (int)rest; g.n = (int)near_cols; g.k = NB;
+            g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_NONE; g.negate = 1; g.accumulate = 1; g.lower_only = 0;
+            if ((rc = gq_sgemm(g, stream))) return rc;
+        }
+        // at the end of a super-panel: everything beyond it, with all of its panels at once
+        if (j + 1 == sp_end && sp_end < nb) {
+            const int64_t s0 = (int64_t)((j / SP) * SP) * NB, e0 = (int64_t)sp_end * NB;
+            float *pfar = linv + e0 * ld + s0;       // L[e0.., s0..e0)
+            g.a = pfar; g.b = pfar; g.c = w + e0 * ld + e0; g.m = (int)(n - e0); g.n = (int)(n - e0); g.k = (int)(e0 - s0);
+            g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_NONE; g.negate = 1; g.accumulate = 1; g.lower_only = 1;
+            if ((rc = gq_sgemm(g, stream))) return rc;
+        }
+    }
+    // node at block offset ob with a complete left part of n1 blocks and a complete right part of n2
+    // blocks, `batch` of them `spacing` blocks apart
+    auto join = [&](int64_t ob, int64_t n1, int64_t n2, int batch, int64_t spacing) -> int {
+        const int64_t o = ob * NB, h1 = n1 * NB, h2 = n2 * NB;
+        float *x21 = w + (o + h1) * ld + o;
+        float *i11 = linv + o * ld + o;
+        float *i21 = linv + (o + h1) * ld + o;
+        float *i22 = linv + (o + h1) * ld + o + h1;
+        g.batch = batch;
+        g.stride_a = g.stride_b = g.stride_c = spacing * NB * (ld + 1);
+        // X = L21 * L11^-1          out[i][j] = sum_k L21[i][k] * L11inv[k][j],  k >= j
+        g.a = i21; g.b = i11; g.c = x21; g.m = (int)h2; g.n = (int)h1; g.k = (int)h1;
+        g.layout = GQ_A_MK | GQ_B_KN; g.trim = GQ_TRIM_K_GE_N; g.negate = 0; g.accumulate = 0; g.lower_only = 0;
+        int r = gq_sgemm(g, stream);
+        if (r) return r;
+        // (L^-1)21 = -L22^-1 * X    out[i][j] = -sum_k L22inv[i][k] * X[k][j],  k <= i
+        g.a = i22; g.b = x21; g.c = i21; g.m = (int)h2; g.n = (int)h1; g.k = (int)h2;
+        g.layout = GQ_A_MK | GQ_B_KN; g.trim = GQ_TRIM_K_LE_M; g.negate = 1; g.accumulate = 0; g.lower_only = 0;
+        return gq_sgemm(g, stream);
+    };
+    for (int64_t half = 1; 2 * half <= nb; half *= 2)   // aligned complete nodes of 2 * half blocks
+        if ((rc = join(0, half, half, (int)(nb / (2 * half)), 2 * half))) return rc;
+    // the complete subtrees are the bits of nb, largest first; join them from the right
+    int64_t right_o = -1, right_n = 0;
+    for (int64_t bit = 1, end = nb; bit <= nb; bit *= 2) {
+        if (!(nb & bit)) continue;
+        const int64_t o = end - bit;   // this subtree covers blocks [end - bit, end)
+        if (right_o >= 0 && (rc = join(o, bit, right_n, 1, 0))) return rc;
+        right_o = o;
+        right_n += bit;
+        end = o;
+    }
+    return GQ_OK;
+}
+
 struct InvertWorkspace {
     float *t;        // c * c     gather target
     float *w;        // cp * cp   reversed work matrix
@@ -564,7 +655,12 @@ int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm
         GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
         hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
         GQ_LAUNCH_CHECK();
-        int rc = cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream);
+        static const bool recursive = [] {   // experiments: GQ_INVERT=rec selects the recursive form
+            const char *e = getenv("GQ_INVERT");
+            return e && e[0] == 'r';
+        }();
+        int rc = recursive ? cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream)
+                           : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv, ws.status);
         GQ_LAUNCH_CHECK();

@@ -29,6 +29,10 @@ struct GqSgemmArgs {
     int negate;       // C = beta*C - A*B instead of + A*B
     int accumulate;   // beta = 1 (C is read and is the start of every element's fma chain) else 0
     int lower_only;   // only tiles with tm >= tn are computed (symmetric rank-k update)
+    // batch of independent products of the same shape: product z works on a + z * stride_a, ... (floats);
+    // batch == 0 means 1
+    int batch;
+    int64_t stride_a, stride_b, stride_c;
 };
 
 // Every element of C is produced by ONE k-ascending chain  c = fma(+-a[m][k], b[k][n], c)

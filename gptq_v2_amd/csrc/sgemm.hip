@@ -11,6 +11,8 @@
 //   row-contiguous source (A_KM, B_KN): [32 k][128 floats]    read at k*128 + row
 #include <type_traits>
 
+#include <algorithm>
+
 #include "sgemm.h"
 
 namespace {
@@ -45,6 +47,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    g.a += (int64_t)blockIdx.y * g.stride_a;
+    g.b += (int64_t)blockIdx.y * g.stride_b;
+    g.c += (int64_t)blockIdx.y * g.stride_c;
     int tm, tn;
     if (g.lower_only) {
         const int bid = blockIdx.x;
@@ -315,7 +320,7 @@ int launch_sgemm(const GqSgemmArgs &args, hipStream_t stream)
     default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
     }
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(256), LDS_BYTES, stream, args, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(n_blocks, std::max(args.batch, 1)), dim3(256), LDS_BYTES, stream, args, tiles_m, tiles_n);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
@@ -342,7 +347,10 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
     if (args.m == 0 || args.n == 0) return GQ_OK;
     // 128-tiles unless they would occupy fewer than the chip's 256 CUs
     const int64_t tm = (args.m + 127) / 128, tn = (args.n + 127) / 128;
-    const int64_t blocks128 = args.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    GQ_REQUIRE(args.batch >= 0 && args.batch <= 65535, "sgemm: batch %d", args.batch);
+    GQ_REQUIRE(args.batch <= 1 || (args.stride_a % 4 == 0 && args.stride_b % 4 == 0 && args.stride_c % 4 == 0),
+               "sgemm: batch strides must be multiples of 4");
+    const int64_t blocks128 = (args.lower_only ? tm * (tm + 1) / 2 : tm * tn) * std::max(args.batch, 1);
     if (blocks128 < 256) return launch_sgemm<64>(args, stream);
     return launch_sgemm<128>(args, stream);
 }
