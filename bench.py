@@ -77,7 +77,20 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    raise SystemExit(subprocess.call(cmd, env=env))
+    # the ranks' stdout is read here so that exactly one line, rank 0's JSON, reaches this process's
+    # stdout (the gloo backend writes connection notices to stdout); everything else goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    result = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            result = line
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if result is not None:
+        sys.stdout.write(result)
+        sys.stdout.flush()
+    raise SystemExit(rc if rc else (0 if result is not None else 1))
 
 
 class Phase:
