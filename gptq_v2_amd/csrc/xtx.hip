@@ -265,17 +265,19 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
 
 // ---- 256 x 256 tiles -------------------------------------------------------------------------
 // Same construction with half the L2 -> LDS bytes per flop: 512 threads, 8 waves as 2 (rows) x 4
-// (columns), each wave a 128 x 64 sub-tile (4 x 2 MFMA blocks, 128 accumulator registers), 32-token
+// (columns), each wave a 128 x 64 sub-tile of 8 x 4 blocks on v_mfma_f32_16x16x32 (one MFMA spans the
+// whole 32-token step, so an accumulator is read and written once per 32 tokens: 3 % faster than the
+// same tile on 32 x 32 x 16 blocks, measured at both widths), 128 accumulator registers, 32-token
 // steps, 4 LDS stages of 32 KiB (one workgroup per CU, three steps of DMA in flight).
 // LDS rows are 512 bytes (256 columns); the 32-byte chunk index is XOR-ed with 2 * (k & 3) as in
 // the 128-column image (only the low three bits matter for the banks).
 //
 // Schedule.  A step is two segments separated by workgroup barriers: R (the 24 transposing LDS
-// reads of the step) and M (its 16 MFMAs).  Waves 4..7 run one segment behind waves 0..3 (one
+// reads of the step) and M (its 32 MFMAs).  Waves 4..7 run one segment behind waves 0..3 (one
 // extra barrier in front of their loop, waves 0..3 take theirs at the end); waves w and w + 4
 // share a SIMD, so one of them is always in M while the other is in R: the matrix pipe has work
 // all the time and the partner's LDS traffic runs beside it.  The LDS-DMA loads of step t + 3 are
-// issued from inside M(t), one between every four MFMAs: there the wave only waits for the matrix
+// issued from inside M(t), one between every eight MFMAs: there the wave only waits for the matrix
 // pipe, so issuing costs nothing and the address unit sees an even trickle (issued at the head of
 // a read segment the same loads delay the reads behind them by hundreds of cycles).
 // Ordering: stage (t+3) % 4 held step t-1, whose last reads (R(t-1) of waves 4..7) ended before a
@@ -298,44 +300,6 @@ __device__ __forceinline__ void stage_one2(const unsigned short *__restrict__ x,
     const int chunk = (s >> 1) ^ (2 * (k & 3));
     const unsigned short *src = x + (tok0 + k) * ld + col0 + chunk * 16 + (s & 1) * 8;
     __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(src), GQ_LDS_PTR(void, lds_op + ii * 1024), 16, 0, 0);
-}
-
-struct Frags2 {
-    s16x4 a[4][2], b[2][2];
-};
-
-template <int BASE>
-__device__ __forceinline__ void read_step2(Frags2 &f, const unsigned (&addrA)[4], const unsigned (&addrB)[2])
-{
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        tr_read<BASE>(f.a[u][0], addrA[u]);
-        tr_read<BASE + 4 * 512>(f.a[u][1], addrA[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        tr_read<BASE + OP2_BYTES>(f.b[u][0], addrB[u]);
-        tr_read<BASE + OP2_BYTES + 4 * 512>(f.b[u][1], addrB[u]);
-    }
-}
-
-// the 8 MFMAs of one 16-token chunk; `between(0)` / `between(1)` run after the 2nd and the 6th
-template <int DTYPE, typename Hook>
-__device__ __forceinline__ void mfma_step2(f32x16 (&acc)[4][2], const Frags2 &f, Hook between)
-{
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const s16x8 fa = __builtin_shufflevector(f.a[a][0], f.a[a][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            const s16x8 fb = __builtin_shufflevector(f.b[b][0], f.b[b][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[a][b] = mfma16<DTYPE>(fa, fb, acc[a][b]);
-            if (b == 1 && (a == 0 || a == 2)) {
-                __builtin_amdgcn_sched_barrier(0);
-                between(a >> 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
 }
 
 #ifdef GQ_XTX_TRACE
@@ -380,29 +344,28 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     x += (int64_t)k_begin * BK2 * ld;
     hess += (int64_t)split * part_stride;
 
+    // 16 x 16 x 32 blocks: the 16 lanes of group g hold the 16 columns of a block for tokens 8 g .. 8 g + 7
+    // of the 32-token step (two transposing reads of 4 tokens each)
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-    const int g1 = g & 1, kh = g >> 1;
     const unsigned lds_base = (unsigned)(uintptr_t)GQ_LDS_PTR(char, smem);
-    unsigned addrA[4], addrB[2];
+    unsigned addrA[8], addrB[4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int ca = (wr * 8 + u) ^ (2 * q4);
+        addrA[u] = lds_base + (8 * g + q4) * 512 + ca * 32 + p4 * 8;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int ca = ((wr * 4 + u) * 2 + g1) ^ (2 * q4);
-        addrA[u] = lds_base + (8 * kh + q4) * 512 + ca * 32 + p4 * 8;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int cb = ((wc * 2 + u) * 2 + g1) ^ (2 * q4);
-        addrB[u] = lds_base + (8 * kh + q4) * 512 + cb * 32 + p4 * 8;
+        const int cb = (wc * 4 + u) ^ (2 * q4);
+        addrB[u] = lds_base + (8 * g + q4) * 512 + cb * 32 + p4 * 8;
     }
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // this wave's 4 DMA instructions of step kt: 2 of the row-panel operand, 2 of the column-panel one
     auto issue_one = [&](int kt, char *buf, int i) {
@@ -436,15 +399,20 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
         constexpr int cur = decltype(cur_c)::value;
         constexpr int SB = cur * STAGE2_BYTES;
         // ---- R
-        unsigned sA[4], sB[2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) sA[u] = addrA[u] + SB;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) sB[u] = addrB[u] + SB;
-        Frags2 f0, f1;
+        // stage offsets beyond the 16-bit immediate of the read go into the address
+        constexpr int SB_HI = SB & ~0xFFFF, SB_LO = SB & 0xFFFF;
+        s16x4 fa[8][2], fb[4][2];
         XT_TR(2);
-        read_step2<0>(f0, sA, sB);
-        read_step2<16 * 512>(f1, sA, sB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            tr_read<SB_LO>(fa[u][0], addrA[u] + SB_HI);
+            tr_read<SB_LO + 4 * 512>(fa[u][1], addrA[u] + SB_HI);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            tr_read<SB_LO + OP2_BYTES>(fb[u][0], addrB[u] + SB_HI);
+            tr_read<SB_LO + OP2_BYTES + 4 * 512>(fb[u][1], addrB[u] + SB_HI);
+        }
         XT_TR(3);
         if (kt + 2 < n_ktiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -457,8 +425,22 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
         const bool more = kt + NST2 - 1 < n_ktiles;
         char *nbuf = smem + ((cur + NST2 - 1) % NST2) * STAGE2_BYTES;
         __builtin_amdgcn_s_setprio(1);
-        mfma_step2<DTYPE>(acc, f0, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, i); });
-        mfma_step2<DTYPE>(acc, f1, [&](int i) { if (more) issue_one(kt + NST2 - 1, nbuf, 2 + i); });
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const s16x8 va = __builtin_shufflevector(fa[a][0], fa[a][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8 vb = __builtin_shufflevector(fb[b][0], fb[b][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (DTYPE == GQ_F16)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, va), __builtin_bit_cast(f16x8, vb), acc[a][b], 0, 0, 0);
+                else
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[a][b], 0, 0, 0);
+                if (b == 3 && (a & 1) == 0) {   // behind MFMA 4, 12, 20, 28: one DMA instruction each
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue_one(kt + NST2 - 1, nbuf, a >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         __builtin_amdgcn_s_setprio(0);
         XT_TR(7);
         seg_barrier();
@@ -478,33 +460,33 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     if (!late) __builtin_amdgcn_s_barrier();
     XT_TR(9);
 
-    // H[tile] += acc, one 32 x 32 accumulator block at a time: its 16 loads are issued together
-    // (one memory latency per block, not per element).  Register e of a lane is row
-    // 8*(e>>2) + (e&3) + 4*(lane>>5), column lane&31 of the block, so in the mirrored tile the
-    // four registers e&3 = 0..3 are four consecutive floats of one row: one 16-byte store.
+    // H[tile] += acc.  Register e of a lane is row 4 * (lane >> 4) + e, column lane & 15 of the 16 x 16
+    // block, so in the mirrored tile the four registers are four consecutive floats of one row: one
+    // 16-byte store.  The loads of four blocks are issued together.
     const bool do_mirror = mirror && (ti != tj);
-    const int lrow = 4 * (lane >> 5), lcol = lane & 31;
+    const int lrow = 4 * (lane >> 4), lcol = lane & 15;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a) {
+        float old[4][4];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int row0 = m0 + (wr * 4 + a) * 32 + lrow;
-            const int col = n0 + (wc * 2 + b) * 32 + lcol;
-            float *p0 = hess + (int64_t)row0 * ld + col;
-            float old[16];
+        for (int b = 0; b < 4; ++b) {
+            const float *p0 = hess + (int64_t)(m0 + wr * 128 + a * 16 + lrow) * ld + n0 + wc * 64 + b * 16 + lcol;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] = p0[(int64_t)((e & 3) + 8 * (e >> 2)) * ld];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] += acc[a][b][e];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) p0[(int64_t)((e & 3) + 8 * (e >> 2)) * ld] = old[e];
-            if (do_mirror) {
-                float *q0 = hess + (int64_t)col * ld + row0;
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4)
-                    *reinterpret_cast<f32x4 *>(q0 + 8 * e4) = f32x4{old[4 * e4], old[4 * e4 + 1], old[4 * e4 + 2], old[4 * e4 + 3]};
-            }
+            for (int e = 0; e < 4; ++e) old[b][e] = p0[(int64_t)e * ld];
         }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row0 = m0 + wr * 128 + a * 16 + lrow, col = n0 + wc * 64 + b * 16 + lcol;
+            float *p0 = hess + (int64_t)row0 * ld + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                old[b][e] += acc[a][b][e];
+                p0[(int64_t)e * ld] = old[b][e];
+            }
+            if (do_mirror)
+                *reinterpret_cast<f32x4 *>(hess + (int64_t)col * ld + row0) = f32x4{old[b][0], old[b][1], old[b][2], old[b][3]};
+        }
+    }
 #ifdef GQ_XTX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XT_TR(10);
@@ -652,9 +634,10 @@ int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64
     // panels of X instead of 64, and the XCD's L2 serves the rest (measured: fewest memory-side bytes)
     int rc = get_tile_table(nt, compute_lower_only, 6, &table, &n_blocks);
     if (rc) return rc;
-    GQ_HIP(hipFuncSetAttribute((const void *)xtx256_kernel<DTYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
-    hipLaunchKernelGGL(xtx256_kernel<DTYPE>, dim3(n_blocks * n_splits), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden,
-                       n_ktiles, table, n_blocks * n_splits, mirror, n_blocks, n_splits, part_stride);
+    auto kern = xtx256_kernel<DTYPE>;
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
+    hipLaunchKernelGGL(kern, dim3(n_blocks * n_splits), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles, table,
+                       n_blocks * n_splits, mirror, n_blocks, n_splits, part_stride);
     GQ_LAUNCH_CHECK();
     done = (int64_t)n_ktiles * BK2;
     return GQ_OK;
