@@ -126,6 +126,21 @@ def _row_slices(n_rows: int, want: int) -> list:
     return [(b, min(n_rows, b + step)) for b in range(0, n_rows, step)]
 
 
+_const_cache: dict = {}
+
+
+def _const_tensor(values, dtype: torch.dtype, device) -> torch.Tensor:
+    """A small constant tensor (group sizes, bit widths) on ``device``: uploaded once per distinct list and
+    cloned on the device afterwards, instead of one host-to-device copy per Linear."""
+    key = (tuple(values), dtype, str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 256:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.as_tensor(list(values), dtype=dtype, device=device)
+    return t.clone()
+
+
 @torch.no_grad()
 def gptq_quant_set(
         weights,
@@ -202,12 +217,15 @@ def gptq_quant_set(
         main.wait_stream(st)
 
     out = []
+    # one device-to-host round trip for the metric sums of the whole set, one conversion of perm_inv
+    all_sums = torch.stack([j[2] for j in jobs]).tolist()
+    perm_inv_set = hessian_hook.perm_inv.to(torch.int16) if perm32 is not None else None
     for wi, weight in enumerate(weights):
         mine = [j for j in jobs if j[0] == wi]
         n_rows, n_columns = weight.shape
         dtype = weight.dtype
         cat = (lambda name: mine[0][1][name][:n_rows]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0)[:n_rows])
-        sums = torch.stack([j[2] for j in mine]).sum(dim=0).tolist()
+        sums = [sum(all_sums[k][i] for k, j in enumerate(jobs) if j[0] == wi) for i in range(4)]
         n = float(n_rows * n_columns)
         gptq_error = sums[0] / n
         metrics = {
@@ -218,7 +236,7 @@ def gptq_quant_set(
             "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(dtype).item(),
         }
         if perm32 is not None:
-            perm_inv = hessian_hook.perm_inv.to(torch.int16)
+            perm_inv = perm_inv_set
         else:
             perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
         qweight, scale, qzero = cat("qweight"), cat("scale"), cat("qzero")
@@ -253,8 +271,8 @@ def gptq_quant_set(
             "qscale": None if qscale is None else qscale.to(device=save_device),
             "sscale": None if sscale is None else sscale.to(device=save_device),
             "perm_inv": perm_inv.to(device=save_device),
-            "group_sizes": torch.as_tensor(out_gs, dtype=torch.int16, device=save_device),
-            "group_bit_widths": torch.as_tensor(out_gb, dtype=torch.uint8, device=save_device),
+            "group_sizes": _const_tensor(out_gs, torch.int16, save_device),
+            "group_bit_widths": _const_tensor(out_gb, torch.uint8, save_device),
             "scale_bit_width": sbw,
         }
         out.append({"quant_meta": quant_meta, "metrics": metrics})
