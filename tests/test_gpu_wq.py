@@ -141,3 +141,23 @@ def test_stream_kernel_products(amd, gpu, bits, dtype, m, r, c, gsz):
         finally:
             lib.gq_set_wq_kernel(before)
         assert (y2.double() - y.double()).abs().max() <= tol * ref.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("bits", [3, 4])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_stream_kernel_every_k_step_count(amd, gpu, bits, dtype):
+    """1 to 12 k-steps (the stream kernel peels its first and its last two to four steps, by parity): the
+    product with an identity-like input returns the dense weight bit for bit at every count."""
+    lib = amd._lib.load()
+    before = lib.gq_set_wq_kernel(1)
+    try:
+        for steps in range(1, 13):
+            c, r, gsz = 64 * steps, 264, 32 if steps % 2 else 64
+            meta = _random_layer(amd, gpu, r, c, gsz, bits, dtype, 100 * steps + bits)
+            w = amd.quant.reconstruct_weight(meta, dtype, gpu)
+            packed = amd.ops.pack_rows(meta["qweight"], bits, amd.ops.PACK_W4_KBLOCK if bits == 4 else amd.ops.PACK_W3_KBLOCK)
+            y = amd.ops.w4a16_gemm(torch.eye(c, dtype=dtype, device=gpu), packed, meta["scale"].t().contiguous(),
+                                   meta["qzero"].t().contiguous(), gsz, bits=bits)
+            assert torch.equal(y, w.t()), steps
+    finally:
+        lib.gq_set_wq_kernel(before)
