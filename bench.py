@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving", action="store_true")
-    ap.add_argument("--replay", choices=("dense", "packed"), default="dense",
-                    help="dense: x W^T on the reconstructed weight (what the reference runs); packed: the W4A16 GEMM")
+    ap.add_argument("--replay", choices=("dense", "packed", "lib"), default="dense",
+                    help="dense: x W^T on the reconstructed weight (what the reference runs); packed: the W4A16 GEMM; "
+                         "lib: the dense replay through the library's GEMM, for comparison only")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "gemm_nt_traffic.json"),
                     help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run, if present")
     return ap.parse_args()
@@ -186,7 +187,7 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
         # rows of reconstructed weights are stacked and replayed in one launch per batch (each output row
         # is the same dot product either way).  Packed: one gather of the batch into act-order per set,
         # then the W4A16 GEMM per Linear.
-        if args.replay == "dense":
+        if args.replay in ("dense", "lib"):
             if len(dense) > 1 and sum(w.shape[0] for w in dense) <= MERGE_ROWS:
                 with phases["reconstruct"]:
                     dense = [torch.cat(dense, dim=0)]
@@ -194,7 +195,8 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
                 x2 = x[bi:bi + batch].reshape(-1, c)
                 for w in dense:
                     with phases["replay_gemm"]:
-                        y = amd.ops.gemm_nt(x2, w)
+                        # "lib": the library's fp16 GEMM on the same operands, a reference point for the kernel
+                        y = amd.ops.gemm_nt(x2, w) if args.replay == "dense" else torch.matmul(x2, w.t())
                     flops[0] += 2.0 * x2.shape[0] * w.shape[0] * c
                     del y
         else:
@@ -392,8 +394,9 @@ def main():
         # both as means over the launches of a block
         pr = phases["replay_gemm"]
         replay_tflops = flops[0] / (pr.total_ms() * 1e-3) / 1e12 if pr.count() else 0.0
-        replay_kernel = "gemm_nt_kernel (y = x W^T on the reconstructed fp16 weight" if args.replay == "dense" else \
-                        "w4a16_256_kernel (y = x W4^T"
+        replay_kernel = {"dense": "gemm_nt_kernel (y = x W^T on the reconstructed fp16 weight",
+                         "lib": "the library's fp16 GEMM (torch.matmul; comparison run, not the product path",
+                         "packed": "w4a16_256_kernel (y = x W4^T"}[args.replay]
         line = {
             "metric": "llama2_%s_w%dg128_quantize_wallclock" % (args.model, args.bits),
             "value": round(ms_per_step * n_blocks / 1e3, 3),

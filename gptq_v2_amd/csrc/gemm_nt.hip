@@ -22,14 +22,33 @@
 // other stage is complete for the reads that the fourth quarter issues.
 //
 // Measured at 32768 tokens (MI355X, synthetic activations): 2280-2320 cycles per k-step against 2048
-// of pure MFMA issue, at a clock of 1.35-1.5 GHz -- the launch is limited by the power the chip may
-// draw, not by issue slots, so what moves its speed is energy per flop: v_mfma_f32_16x16x32 in
-// place of 32x32x16 at the same wave tile gave 5-7 %, immediate offsets in place of address
-// arithmetic for the fragment reads 1-3 %; a four-barrier read / MFMA role split of the two waves
-// of a SIMD was 4-8 % slower, a persistent grid that pipelines across tile boundaries 5 % slower
-// (the idle time between tiles costs no energy), four waves of 128 x 128 (a third fewer LDS bytes
-// per flop, one wave per SIMD) 3 % slower, non-temporal stores of y 3-7 % slower and non-temporal loads of
-// either operand 10-18 % slower (the re-reads of x and w are served by the caches the hint bypasses).
+// of pure MFMA issue, at a clock of 1.35-1.7 GHz -- the launch is limited by the power the chip may
+// draw, not by issue slots.  The same loop with its loads, fragment reads and waits all removed (MFMAs
+// only, on one wave per SIMD) reaches 1385-1395 TFLOP/s over back-to-back launches, 0.56 of the
+// nominal peak: that is the ceiling for this instruction under the cap; this kernel holds 1250-1340
+// there, the library's GEMM 1340-1390.  The matrix pipe is busy 0.67-0.76 of the cycles here and
+// 0.78-0.89 in the library's kernel, which runs at a correspondingly lower clock (1.5-1.6 against
+// 1.7-1.85 GHz): idle cycles are not free, they move the chip to a higher, less efficient voltage.
+// What moved the speed: v_mfma_f32_16x16x32 in place of 32x32x16 at the same wave tile gave 5-7 %,
+// immediate offsets in place of address arithmetic for the fragment reads 1-3 %, bands of 3 tile
+// rows instead of 2 0.5-3 % (bands of 4 need the XCDs to start at different k to match that: without
+// the stagger all eight fetch the same w panels at once and lose 5 %).  What did not: a four-barrier read / MFMA role split of the two waves
+// of a SIMD (4-8 % slower); non-temporal stores of y (3-7 % slower) and non-temporal loads of either
+// operand (10-18 % slower: the re-reads of x and w are served by the caches the hint bypasses); four
+// waves of 128 x 128 with the accumulators in 256 hand-assigned AGPRs (the library's shape: a third
+// fewer LDS bytes per flop), as a persistent grid of one workgroup per CU that fetches the next
+// tile's first two k-steps during the last two of the current one: equal to this kernel within 1 %
+// when launches are interleaved with other work, 8 % slower back to back, and the persistent grid
+// changed neither its cycles nor its pipe occupancy (0.71-0.74) -- prologue and epilogue are not what
+// is lost.  In that kernel, dropping the DMA issue alone gained 13-18 %, dropping the fragment reads
+// alone 9 %, dropping the wait for the DMA nothing: the cost of the loads is the power their traffic
+// draws, not their latency.  (6.3 GB are fetched past the L2 per 12288-row launch with bands of 2 and
+// the library's tile order fetches 36 % less, but bands of 4 or 8 with the stagger, which fetch a third
+// less too, change nothing measurable, in isolation or inside the whole quantisation step.)
+// (For such experiments: accumulators bound to inline-asm MFMAs as C++ variables are moved between
+// registers by hipcc, which does not know that the asm is a matrix instruction still in flight, and
+// come out wrong; through the builtin every result gets a register of its own and three moves per
+// MFMA put them back.  Hard-coded a[N:N+3] operands with a clobber list of all AGPRs work.)
 #include <algorithm>
 #include <type_traits>
 
@@ -313,6 +332,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
 }
 
 
+
 }  // namespace
 
 #ifdef GQ_NT_TRACE
@@ -340,7 +360,9 @@ extern "C" int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int6
         const char *e = getenv("GQ_NT_BAND");
         return e ? atoi(e) : 0;
     }();
-    const int band = band_env > 0 ? band_env : 2;
+    // tile rows per band, measured over back-to-back launches at 32768 tokens: 3 beats 2 by 0.5-1 % on the
+    // wide shapes (and 4, 5, 6, 8 lose 2-7 % there); the 16-tile-wide, 4096-deep launch gains 6 % from 4
+    const int band = band_env > 0 ? band_env : (tiles_n <= 16 && k <= 4096 ? 4 : 3);
     auto kern = dtype == GQ_F16 ? gemm_nt_kernel<GQ_F16> : gemm_nt_kernel<GQ_BF16>;
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, N_LDS));
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), N_LDS, (hipStream_t)stream, (unsigned short *)y,

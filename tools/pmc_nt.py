@@ -1,5 +1,5 @@
 """Three launches of the dense replay GEMM per launch shape of a Llama-2-7B block at the bench's M
-(32768 tokens): merged q/k/v (12288 x 4096), o (4096 x 4096), gate and up (11008 x 4096 each), down
+(32768 tokens; GQ_PMC_LIB=1: the library GEMM on the same data): merged q/k/v (12288 x 4096), o (4096 x 4096), gate and up (11008 x 4096 each), down
 (4096 x 11008); for rocprofv3 --pmc passes.  `summarize <dir> <counter>` prints the per-shape mean."""
 import collections, csv, glob, os, sys
 
@@ -14,7 +14,7 @@ def run():
         x = (torch.randn(m, c, device=dev) * (1 + 3 * torch.arange(c, device=dev) / c)).half()
         w = (torch.randn(r, c, device=dev) * 0.02).half()
         for _ in range(3):
-            amd.ops.gemm_nt(x, w)
+            torch.matmul(x, w.t()) if os.environ.get("GQ_PMC_LIB") else amd.ops.gemm_nt(x, w)
         torch.cuda.synchronize()
         del x, w
 
@@ -24,8 +24,8 @@ def summarize(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "gemm_nt" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                acc[int(row["Grid_Size"]) // 512].append(float(row["Counter_Value"]))
+            if ("gemm_nt" in row["Kernel_Name"] or "Cijk" in row["Kernel_Name"]) and row["Counter_Name"] == counter:
+                acc[(row["Kernel_Name"][:24], int(row["Grid_Size"]) // int(row["Workgroup_Size"]))].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print(counter, "workgroups", k, "n", len(v), "mean", sum(v) / len(v))
 
