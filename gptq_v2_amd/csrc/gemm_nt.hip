@@ -30,7 +30,9 @@
 // 0.78-0.89 in the library's kernel, which runs at a correspondingly lower clock (1.5-1.6 against
 // 1.7-1.85 GHz): idle cycles are not free, they move the chip to a higher, less efficient voltage.
 // What moved the speed: v_mfma_f32_16x16x32 in place of 32x32x16 at the same wave tile gave 5-7 %,
-// immediate offsets in place of address arithmetic for the fragment reads 1-3 %, bands of 3 tile
+// immediate offsets in place of address arithmetic for the fragment reads 1-3 %, the persistent grid
+// with the next tile's loads in flight over the epilogue (and buffer loads whose tile and k-step are
+// scalar operands, in place of a 64-bit address per piece and lane) 1.2-3 %, bands of 3 tile
 // rows instead of 2 0.5-3 % (bands of 4 need the XCDs to start at different k to match that: without
 // the stagger all eight fetch the same w panels at once and lose 5 %).  What did not: a four-barrier read / MFMA role split of the two waves
 // of a SIMD (4-8 % slower); non-temporal stores of y (3-7 % slower) and non-temporal loads of either
@@ -38,9 +40,9 @@
 // waves of 128 x 128 with the accumulators in 256 hand-assigned AGPRs (the library's shape: a third
 // fewer LDS bytes per flop), as a persistent grid of one workgroup per CU that fetches the next
 // tile's first two k-steps during the last two of the current one: equal to this kernel within 1 %
-// when launches are interleaved with other work, 8 % slower back to back, and the persistent grid
-// changed neither its cycles nor its pipe occupancy (0.71-0.74) -- prologue and epilogue are not what
-// is lost.  In that kernel, dropping the DMA issue alone gained 13-18 %, dropping the fragment reads
+// when launches are interleaved with other work, 8 % slower back to back (one wave per SIMD exposes
+// every wait of its own; its pipe occupancy stayed at 0.71-0.74 with or without the persistent grid).
+// In that kernel, dropping the DMA issue alone gained 13-18 %, dropping the fragment reads
 // alone 9 %, dropping the wait for the DMA nothing: the cost of the loads is the power their traffic
 // draws, not their latency.  (6.3 GB are fetched past the L2 per 12288-row launch with bands of 2 and
 // the library's tile order fetches 36 % less, but bands of 4 or 8 with the stagger, which fetch a third
@@ -78,12 +80,6 @@ __device__ __forceinline__ void nt_read_b128_off(u32x4 &dst, unsigned lds_addr)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
 }
 
-#ifdef GQ_NT_TRACE
-// Debug build only (tools/trace_nt.py): per-workgroup time stamps (100 MHz real-time counter) and
-// the hardware ids of the CU it ran on.
-__device__ unsigned long long *g_nt_trace = nullptr;
-#endif
-
 // The wave's 128 x 64 sub-tile is 8 (x rows) x 4 (w rows) blocks of 16 x 16; a k-step is two 32-deep
 // chunks, a chunk two halves of 16 MFMAs (4 x-row blocks each against the chunk's 4 w-row blocks).
 // A operand = w rows, B operand = x rows, so a lane of the result holds 4 consecutive output
@@ -91,41 +87,52 @@ __device__ unsigned long long *g_nt_trace = nullptr;
 // parity) and two sets of x fragments (by half); each set is loaded while the other is in use.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Persistent grid: one workgroup per CU walks its share of the tiles as ONE stream of k-steps.  The
+// pieces of the next tile's first two k-steps are fetched during the last two of the current one, so a
+// tile's epilogue and the next tile's first loads overlap and the LDS pipeline never drains.  The DMA
+// goes through buffer loads (bounds-checked: rows past the end of an operand read as zero instead of
+// being clamped per lane, so the lane offsets are the same for every tile; the tile and the k-step are
+// scalar operands of the load).
+typedef __amdgpu_buffer_rsrc_t nt_rsrc_t;
+
 template <int DT>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
-                                                       const unsigned short *__restrict__ w, int64_t m_total, int64_t n_total,
-                                                       int64_t k_total, int tiles_n, int n_blocks, int band)
+                                                        const unsigned short *__restrict__ w, int64_t m_total, int64_t n_total,
+                                                        int64_t k_total, int tiles_n, int n_blocks, int band)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef GQ_NT_TRACE
-    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    int bid;
+    // workgroup `orig` sits on XCD orig & 7 (round-robin dispatch) in slot orig >> 3.  An XCD owns a
+    // contiguous run of the band-ordered tile list and its slots walk that run round-robin, so the tiles
+    // in flight on an XCD at any time are neighbours that share x and w panels in its L2.
+    int tile0, tile_end, tile_step;
     {
-        const int orig = blockIdx.x, xcd = orig & 7;
+        const int orig = blockIdx.x, xcd = orig & 7, slot = orig >> 3;
         const int q = n_blocks >> 3, r = n_blocks & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_step = ((int)gridDim.x + 7 - xcd) >> 3;
+        tile0 = start + slot;
+        tile_end = start + q + (xcd < r ? 1 : 0);
     }
-    int tm, tn;
-    {
+    if (tile0 >= tile_end) return;   // the whole workgroup leaves: no barrier is left waiting
+    const int tiles_m = n_blocks / tiles_n;
+    auto tile_origin = [&](int bid, int64_t &m0, int64_t &n0) __attribute__((always_inline)) {
         const int per_band = band * tiles_n;
         const int b = bid / per_band, within = bid - b * per_band;
-        const int tiles_m = n_blocks / tiles_n;
         const int rows = min(band, tiles_m - b * band);
-        tn = within / rows;
-        tm = b * band + (within - tn * rows);
-    }
-    const int64_t m0 = (int64_t)tm * NT, n0 = (int64_t)tn * NT;
+        const int tn = within / rows;
+        m0 = (int64_t)(b * band + (within - tn * rows)) * NT;
+        n0 = (int64_t)tn * NT;
+    };
     const int n_ktiles = (int)(k_total / NK);
+    const int my_tiles = (tile_end - tile0 + tile_step - 1) / tile_step;
+    const int n_steps = my_tiles * n_ktiles;   // < 2^31: checked by the launcher
 
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
     const unsigned lds_base = (unsigned)(uintptr_t)GQ_LDS_PTR(char, smem);
-    // fragment of block u, chunk c: row (block base + l15), 16-byte chunk (4 c + lg) ^ ((row >> 1) & 7);
-    // block bases are multiples of 16 rows, so the swizzle term is ((l15 >> 1) & 7) for every block
     const int sw = (l15 >> 1) & 7;
     const unsigned xrow = lds_base + (wr * 128 + l15) * 128;               // + u * 2048, u = 0..7
     const unsigned wrow = lds_base + N_OP_BYTES + (wc * 64 + l15) * 128;   // + u * 2048, u = 0..3
@@ -134,30 +141,40 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
     for (int c = 0; c < 2; ++c) choff[c] = (unsigned)(((4 * c + lg) ^ sw) << 4);
 
     f32x4v acc[4][8];   // [w block][x block]
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    // DMA source addressing: a wave-uniform 64-bit base (the tile's first row at the current k) plus one
-    // 32-bit byte offset per piece and lane, fixed for the whole tile (row, clamped to the last row of
-    // the operand, and swizzled chunk); the host checks that 256 rows stay below 2^31 bytes
-    const unsigned short *xt = x + m0 * k_total, *wt = w + n0 * k_total;
-    unsigned voff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (wave * 4 + (i & 3)) * 8 + (lane >> 3);
-        const int64_t lim = (i < 4 ? m_total - m0 : n_total - n0) - 1;
-        const int rc = (int)(row < lim ? row : lim);
-        voff[i] = (unsigned)rc * (unsigned)(k_total * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-    }
-    auto dma = [&](int kt, char *stage, int i) {
-        const char *base = reinterpret_cast<const char *>((i < 4 ? xt : wt) + (int64_t)kt * NK);
-        char *dst = stage + (i < 4 ? 0 : N_OP_BYTES) + (wave * 4 + (i & 3)) * 1024;
-        __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(base + voff[i]), GQ_LDS_PTR(void, dst), 16, 0, 0);
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
     };
+    zero_acc();
+
+    // DMA source: a buffer descriptor per operand and tile (base = the tile's first row, extent = the rest
+    // of the operand), one 32-bit byte offset per piece and lane (row within the tile, swizzled chunk) and
+    // the k-step as the scalar offset
+    unsigned voff[4];   // piece j of either operand: rows (wave * 4 + j) * 8 + (lane >> 3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        voff[j] = (unsigned)row * (unsigned)(k_total * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    auto rsrc_of = [&](const unsigned short *base, int64_t first_row, int64_t rows_total) __attribute__((always_inline)) {
+        const int64_t bytes = (rows_total - first_row) * k_total * 2;
+        const unsigned recs = (unsigned)(bytes < (int64_t)0xFFFFFFFFll ? bytes : (int64_t)0xFFFFFFFFll);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + first_row * k_total), 0, (int)recs, 0x00020000);
+    };
+    auto dma_piece = [&](nt_rsrc_t rs, int kt, char *dst, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, GQ_LDS_PTR(void, dst), 16, (int)voff[j], kt * (NK * 2), 0, 0);
+    };
+    // x pieces 0..3 of a k-step, then its w pieces 0..3
+    auto dma_x = [&](nt_rsrc_t rx, int kt, char *stage, int j) __attribute__((always_inline)) {
+        dma_piece(rx, kt, stage + (wave * 4 + j) * 1024, j);
+    };
+    auto dma_w = [&](nt_rsrc_t rw, int kt, char *stage, int j) __attribute__((always_inline)) {
+        dma_piece(rw, kt, stage + N_OP_BYTES + (wave * 4 + j) * 1024, j);
+    };
+
     u32x4 fw[2][4], fx[2][4];   // fw[chunk parity][w block], fx[half][x block of the half]
-    // block u of an image is u * 2048 bytes behind block 0: an immediate offset of the read
     auto read_w = [&](int set, unsigned sb, int c, int u) __attribute__((always_inline)) {
         const unsigned addr = wrow + sb + choff[c];
         switch (u) {
@@ -176,8 +193,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
         default: nt_read_b128_off<6144>(fx[half][3], addr); break;
         }
     };
-    // 16 MFMAs: x blocks of `half` against the w blocks of set `ws`; hook(i) runs behind MFMA i
-    auto half_step = [&](int ws, int half, auto hook) {
+    auto half_step = [&](int ws, int half, auto hook) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -195,20 +211,46 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-    auto reads_done = [&]() {
+    auto reads_done = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // fetch cursor: the (tile, k-step) two steps ahead of the one being computed
+    int f_tile = tile0, f_kt = 0;
+    nt_rsrc_t f_rx, f_rw;
+    auto fetch_tile = [&](int t) __attribute__((always_inline)) {
+        int64_t m0, n0;
+        tile_origin(t, m0, n0);
+        f_rx = rsrc_of(x, m0, m_total);
+        f_rw = rsrc_of(w, n0, n_total);
+    };
+    auto fetch_advance = [&]() __attribute__((always_inline)) {
+        if (++f_kt == n_ktiles) {
+            f_kt = 0;
+            f_tile += tile_step;
+            if (f_tile < tile_end) fetch_tile(f_tile);
+        }
+    };
+    fetch_tile(f_tile);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma(0, smem, i);
-    if (n_ktiles > 1) {
+    for (int j = 0; j < 4; ++j) dma_x(f_rx, 0, smem, j);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma(1, smem + N_STAGE_BYTES, i);
+    for (int j = 0; j < 4; ++j) dma_w(f_rw, 0, smem, j);
+    fetch_advance();
+    if (n_steps > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_x(f_rx, f_kt, smem + N_STAGE_BYTES, j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_w(f_rw, f_kt, smem + N_STAGE_BYTES, j);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // w descriptor and k-step of the step after the one being computed (the fetch cursor's previous value)
+    nt_rsrc_t p_rw = f_rw;
+    int p_kt = f_kt;
+    fetch_advance();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -217,26 +259,26 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
 #pragma unroll
     for (int u = 0; u < 4; ++u) read_x(0, 0u, 0, u);
     reads_done();
-#ifdef GQ_NT_TRACE
-    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime(), tc1 = __builtin_readcyclecounter();
-#endif
 
-    auto body = [&](auto more_c, auto more2_c, auto first_c, int kt) {
+    // One k-step g of the stream.  MORE: step g+1 exists (its first fragments are read here and the w
+    // pieces of it are fetched here unless the prologue did); MORE2: step g+2 exists (its x pieces are
+    // fetched here).
+    auto body = [&](auto more_c, auto more2_c, auto first_c, int g) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
-        const unsigned sb = (unsigned)(kt & 1) * N_STAGE_BYTES, sbn = (unsigned)((kt + 1) & 1) * N_STAGE_BYTES;
-        char *cur = smem + (kt & 1) * N_STAGE_BYTES;
-        char *nxt = smem + ((kt + 1) & 1) * N_STAGE_BYTES;
-        // (chunk 0, half 0): x fragments of (chunk 0, half 1); second half of this wave's pieces of step kt+1
-        half_step(0, 0, [&](int i) {
+        const unsigned sb = (unsigned)(g & 1) * N_STAGE_BYTES, sbn = (unsigned)((g + 1) & 1) * N_STAGE_BYTES;
+        char *cur = smem + (g & 1) * N_STAGE_BYTES;
+        char *nxt = smem + ((g + 1) & 1) * N_STAGE_BYTES;
+        // (chunk 0, half 0): x fragments of (chunk 0, half 1); the w pieces of step g+1
+        half_step(0, 0, [&](int i) __attribute__((always_inline)) {
             if ((i & 1) == 0 && i < 8) read_x(1, sb, 0, i >> 1);
             if constexpr (MORE && !FIRST) {
-                if ((i & 3) == 3) dma(kt + 1, nxt, 4 + (i >> 2));
+                if ((i & 3) == 3) dma_w(p_rw, p_kt, nxt, i >> 2);
             }
         });
         reads_done();
         // (chunk 0, half 1): w fragments of chunk 1, x fragments of (chunk 1, half 0)
-        half_step(0, 1, [&](int i) {
+        half_step(0, 1, [&](int i) __attribute__((always_inline)) {
             if ((i & 1) == 0) {
                 if (i < 8) read_w(1, sb, 1, i >> 1);
                 else read_x(0, sb, 1, (i >> 1) - 4);
@@ -244,17 +286,17 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
         });
         reads_done();
         // (chunk 1, half 0): x fragments of (chunk 1, half 1): the last reads of this stage
-        half_step(1, 0, [&](int i) { if ((i & 1) == 0 && i < 8) read_x(1, sb, 1, i >> 1); });
+        half_step(1, 0, [&](int i) __attribute__((always_inline)) { if ((i & 1) == 0 && i < 8) read_x(1, sb, 1, i >> 1); });
         reads_done();
         if constexpr (MORE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step kt+1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of step g+1
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (chunk 1, half 1): fragments of (chunk 0, half 0) of step kt+1; first half of the pieces of step kt+2
-        half_step(1, 1, [&](int i) {
+        // (chunk 1, half 1): fragments of (chunk 0, half 0) of step g+1; the x pieces of step g+2
+        half_step(1, 1, [&](int i) __attribute__((always_inline)) {
             if constexpr (MORE) {
                 if ((i & 1) == 0) {
                     if (i < 8) read_w(0, sbn, 0, i >> 1);
@@ -262,33 +304,22 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
                 }
             }
             if constexpr (MORE2) {
-                if ((i & 3) == 3) dma(kt + 2, cur, i >> 2);
+                if ((i & 3) == 3) dma_x(f_rx, f_kt, cur, i >> 2);
             }
         });
         if constexpr (MORE) reads_done();
+        if constexpr (MORE2) {
+            p_rw = f_rw;
+            p_kt = f_kt;
+            fetch_advance();
+        }
     };
-    using T = std::true_type;
-    using F = std::false_type;
-    int kt = 0;
-    if (n_ktiles > 2) {
-        body(T{}, T{}, T{}, 0);
-        for (kt = 1; kt + 2 < n_ktiles; ++kt) body(T{}, T{}, F{}, kt);
-        body(T{}, F{}, F{}, kt);
-        ++kt;
-        body(F{}, F{}, F{}, kt);
-    } else if (n_ktiles == 2) {
-        body(T{}, F{}, T{}, 0);
-        body(F{}, F{}, F{}, 1);
-    } else {
-        body(F{}, F{}, T{}, 0);
-    }
-#ifdef GQ_NT_TRACE
-    const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime(), tc2 = __builtin_readcyclecounter();
-#endif
 
     // lane: token l15 of x block b, output features 4 lg .. 4 lg + 3 of w block a; 32-bit offsets from
     // the wave's corner of the tile
-    {
+    auto store_tile = [&](int t) __attribute__((always_inline)) {
+        int64_t m0, n0;
+        tile_origin(t, m0, n0);
         unsigned short *yw = y + (m0 + wr * 128) * n_total + n0 + wc * 64;
         const int rows_left = (int)min((int64_t)128, m_total - (m0 + wr * 128));
         const int cols_left = (int)min((int64_t)64, n_total - (n0 + wc * 64));
@@ -316,32 +347,42 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
                 }
             }
         }
+    };
+    int c_tile = tile0, c_kt = 0;   // the tile and k-step being computed
+    auto step_done = [&]() __attribute__((always_inline)) {
+        if (++c_kt == n_ktiles) {
+            store_tile(c_tile);
+            zero_acc();
+            c_kt = 0;
+            c_tile += tile_step;
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (n_steps > 2) {
+        body(T{}, T{}, T{}, 0);
+        step_done();
+        int g = 1;
+        for (; g + 2 < n_steps; ++g) {
+            body(T{}, T{}, F{}, g);
+            step_done();
+        }
+        body(T{}, F{}, F{}, g);
+        step_done();
+        body(F{}, F{}, F{}, g + 1);
+        step_done();
+    } else if (n_steps == 2) {
+        body(T{}, F{}, T{}, 0);
+        step_done();
+        body(F{}, F{}, F{}, 1);
+        step_done();
+    } else {
+        body(F{}, F{}, T{}, 0);
+        step_done();
     }
-#ifdef GQ_NT_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();
-    if (g_nt_trace && tid == 0) {
-        unsigned long long *o = g_nt_trace + (size_t)blockIdx.x * 8;
-        o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3;
-        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-        o[6] = (unsigned long long)bid;
-        o[7] = tc2 - tc1;
-    }
-#endif
 }
-
-
 
 }  // namespace
-
-#ifdef GQ_NT_TRACE
-extern "C" int gq_debug_nt_trace(unsigned long long *buf)
-{
-    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_nt_trace), &buf, sizeof(buf)));
-    return GQ_OK;
-}
-#endif
 
 extern "C" int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int64_t n, int64_t k, int dtype,
                           gq_stream_t stream)
@@ -363,9 +404,18 @@ extern "C" int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int6
     // tile rows per band, measured over back-to-back launches at 32768 tokens: 3 beats 2 by 0.5-1 % on the
     // wide shapes (and 4, 5, 6, 8 lose 2-7 % there); the 16-tile-wide, 4096-deep launch gains 6 % from 4
     const int band = band_env > 0 ? band_env : (tiles_n <= 16 && k <= 4096 ? 4 : 3);
+    static const int grid_env = [] {   // experiment knob: workgroups of the persistent grid
+        const char *e = getenv("GQ_NT_GRID");
+        return e ? atoi(e) : 0;
+    }();
+    int dev = 0, cus = 0;
+    GQ_HIP(hipGetDevice(&dev));
+    GQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int grid = std::min(n_blocks, grid_env > 0 ? grid_env : std::max(cus, 8));
+    GQ_REQUIRE((int64_t)gq_cdiv(n_blocks, grid) * (k / NK) < (1ll << 30), "gq_gemm_nt: too many k-steps per workgroup");
     auto kern = dtype == GQ_F16 ? gemm_nt_kernel<GQ_F16> : gemm_nt_kernel<GQ_BF16>;
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, N_LDS));
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(512), N_LDS, (hipStream_t)stream, (unsigned short *)y,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), N_LDS, (hipStream_t)stream, (unsigned short *)y,
                        (const unsigned short *)x, (const unsigned short *)w, m, n, k, tiles_n, n_blocks, band);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
