@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 for c, n in ((4096, 32768), (4096, 16384), (5120, 32768), (8192, 32768)):
     x = (torch.randn(n, c, device=dev) * (1 + 3 * torch.arange(c, device=dev) / c)).half()
     out = {}
-    for parts in (1, 2, 3, 4, 5):
+    for parts in (1, 2, 3, 4, 5, 7, 9, 11, 13, 15):
         p = torch.zeros(parts, c, c, device=dev)
         f = (lambda: amd.ops.xtx_accumulate(p[0], x)) if parts == 1 else (lambda: amd.ops.xtx_accumulate_split(p, x))
         for _ in range(3): f()
