@@ -47,6 +47,13 @@
 // draws, not their latency.  (6.3 GB are fetched past the L2 per 12288-row launch with bands of 2 and
 // the library's tile order fetches 36 % less, but bands of 4 or 8 with the stagger, which fetch a third
 // less too, change nothing measurable, in isolation or inside the whole quantisation step.)
+// Cycle stamps per phase of a k-step (one wave of each SIMD pair, 12288 x 4096): the two waves of a SIMD do
+// not alternate.  After the barrier the older wave (0-3) wins the matrix pipe whenever it is ready, runs
+// its next three quarters nearly alone and then waits ~780 of the step's ~2300 cycles at the barrier,
+// while the younger one (4-7) runs its quarters alone with its own waits exposed (~150 cycles a step)
+// and arrives last.  Issuing all eight DMA pieces of a step in one quarter instead of four in each of
+// two costs 5-6 %; reading the eight fragments of the two wide quarters back to back instead of one
+// per two MFMAs gains 0.4-0.8 % (within box noise, not kept).
 // (For such experiments: accumulators bound to inline-asm MFMAs as C++ variables are moved between
 // registers by hipcc, which does not know that the asm is a matrix instruction still in flight, and
 // come out wrong; through the builtin every result gets a register of its own and three moves per
