@@ -156,60 +156,77 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
             with phases["allreduce"]:
                 hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
         with phases["invert"]:
-            hook.invert(damp_ratio=1e-2, act_order=True)
+            # enqueued without a host round trip; gptq_quant_set reads the verdict with its metrics
+            hook.invert(damp_ratio=1e-2, act_order=True, wait=False)
         gs = torch.full([c // 128], 128, dtype=torch.int32)
         gb = torch.full([c // 128], args.bits, dtype=torch.int32)
         shards = [gd.row_shard(w.shape[0], rank, world) for w in weights]
         with phases["quant"]:
-            # the Linears of the set share U: all of them are enqueued (row slices on side streams)
-            # before the first result is waited for
+            # the Linears of the set share U: all of them are enqueued (on side streams) and nothing is waited
+            # for; the host goes on to enqueue what consumes the levels and settles the set afterwards
             mine = [(i, w[rb:re]) for i, (w, (rb, re)) in enumerate(zip(weights, shards)) if re > rb]
             part = amd.gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
-                                      gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev)
+                                      gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev,
+                                      wait=False)
+        if world > 1:
+            part.settle()   # the gather over ranks combines the shards' metrics: they have to be there
+        while True:
             by_index = {i: res for (i, _), res in zip(mine, part)}
-        dense, packed = [], []
-        for i, w in enumerate(weights):
-            res = by_index.get(i)
-            if world > 1:
-                with phases["allgather"]:
-                    fields = {"qscale": None, "sscale": None, "scale_bit_width": None,
-                              "perm_inv": hook.perm_inv.to(torch.int16), "group_sizes": gs.to(torch.int16).to(dev),
-                              "group_bit_widths": gb.to(torch.uint8).to(dev)}
-                    res = gd.gather_quant_result(res, fields, w.shape[0], c, w.dtype, dev)
-            meta = res["quant_meta"]
+            set_flops = consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, by_index, hook, gs, gb)
+            # metrics and the verdict of the inversion's first try, read while the replay runs; if that try had
+            # failed the set has been quantised again from the final U and its consumers run once more
+            if part.settle():
+                break
+        flops[0] += set_flops
+        del part, by_index, hook
+
+
+def consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, by_index, hook, gs, gb):
+    """Reconstruct, pack and replay the Linears of one set; returns the replay's flops."""
+    batch = args.batch
+    done = 0.0
+    dense, packed = [], []
+    for i, w in enumerate(weights):
+        res = by_index.get(i)
+        if world > 1:
+            with phases["allgather"]:
+                fields = {"qscale": None, "sscale": None, "scale_bit_width": None,
+                          "perm_inv": hook.perm_inv.to(torch.int16), "group_sizes": gs.to(torch.int16).to(dev),
+                          "group_bit_widths": gb.to(torch.uint8).to(dev)}
+                res = gd.gather_quant_result(res, fields, w.shape[0], c, w.dtype, dev)
+        meta = res["quant_meta"]
+        with phases["reconstruct"]:
+            dense.append(amd.quant.reconstruct_weight(meta, torch.float16, dev))
+        with phases["pack"]:
+            packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True, dense3=args.bits == 3))
+        del meta, res
+    # replay (llama.py:176-177).  Dense: the Linears of a set read the same input, so up to MERGE_ROWS
+    # rows of reconstructed weights are stacked and replayed in one launch per batch (each output row
+    # is the same dot product either way).  Packed: one gather of the batch into act-order per set,
+    # then the W4A16 GEMM per Linear.
+    if args.replay in ("dense", "lib"):
+        if len(dense) > 1 and sum(w.shape[0] for w in dense) <= MERGE_ROWS:
             with phases["reconstruct"]:
-                dense.append(amd.quant.reconstruct_weight(meta, torch.float16, dev))
-            with phases["pack"]:
-                packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True, dense3=args.bits == 3))
-            del meta, res
-        del part, by_index
-        # replay (llama.py:176-177).  Dense: the Linears of a set read the same input, so up to MERGE_ROWS
-        # rows of reconstructed weights are stacked and replayed in one launch per batch (each output row
-        # is the same dot product either way).  Packed: one gather of the batch into act-order per set,
-        # then the W4A16 GEMM per Linear.
-        if args.replay in ("dense", "lib"):
-            if len(dense) > 1 and sum(w.shape[0] for w in dense) <= MERGE_ROWS:
-                with phases["reconstruct"]:
-                    dense = [torch.cat(dense, dim=0)]
-            for bi in range(0, x.shape[0], batch):
-                x2 = x[bi:bi + batch].reshape(-1, c)
-                for w in dense:
-                    with phases["replay_gemm"]:
-                        # "lib": the library's fp16 GEMM on the same operands, a reference point for the kernel
-                        y = amd.ops.gemm_nt(x2, w) if args.replay == "dense" else torch.matmul(x2, w.t())
-                    flops[0] += 2.0 * x2.shape[0] * w.shape[0] * c
-                    del y
-        else:
-            for bi in range(0, x.shape[0], batch):
-                with phases["permute"]:
-                    xp = packed[0].permute_input(x[bi:bi + batch])
-                for layer in packed:
-                    with phases["replay_gemm"]:
-                        y = layer.forward_permuted(xp)
-                    flops[0] += 2.0 * xp.shape[0] * xp.shape[1] * layer.out_features * c
-                    del y
-                del xp
-        del dense, packed, hook
+                dense = [torch.cat(dense, dim=0)]
+        for bi in range(0, x.shape[0], batch):
+            x2 = x[bi:bi + batch].reshape(-1, c)
+            for w in dense:
+                with phases["replay_gemm"]:
+                    # "lib": the library's fp16 GEMM on the same operands, a reference point for the kernel
+                    y = amd.ops.gemm_nt(x2, w) if args.replay == "dense" else torch.matmul(x2, w.t())
+                done += 2.0 * x2.shape[0] * w.shape[0] * c
+                del y
+    else:
+        for bi in range(0, x.shape[0], batch):
+            with phases["permute"]:
+                xp = packed[0].permute_input(x[bi:bi + batch])
+            for layer in packed:
+                with phases["replay_gemm"]:
+                    y = layer.forward_permuted(xp)
+                done += 2.0 * xp.shape[0] * xp.shape[1] * layer.out_features * c
+                del y
+            del xp
+    return done
 
 
 def serving(torch, amd, sets, bits, dev):

@@ -29,6 +29,10 @@ SIGNATURES = {
     "gq_hessian_invert_workspace": (c_size_t, [c_int64]),
     "gq_hessian_invert": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
                                   c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "gq_hessian_invert_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
+                                        c_void_p, c_size_t, c_void_p, c_void_p]),
+    "gq_hessian_invert_finish": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_size_t,
+                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_int), c_void_p]),
     "gq_hessian_invert_static_max_c": (c_int64, []),
     "gq_hessian_invert_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
                                          c_int, ctypes.POINTER(c_int), c_void_p]),

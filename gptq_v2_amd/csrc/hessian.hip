@@ -614,26 +614,29 @@ extern "C" size_t gq_hessian_invert_workspace(int64_t c)
 
 namespace {
 
-int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c, double n_samples,
-                float damp_ratio, int act_order, int max_try, void *workspace, size_t workspace_bytes, int *tries_host,
-                hipStream_t stream, const char *who)
+// argument checks shared by the entry points; carves the workspace
+int invert_setup(InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_t c, void *workspace, size_t workspace_bytes,
+                 const char *who)
 {
     GQ_REQUIRE(hessian && hessian_inv && workspace, "%s: NULL pointer", who);
     GQ_REQUIRE(c > 0 && c <= 32767 * 4, "%s: bad size %lld", who, (long long)c);
-    GQ_REQUIRE(n_samples > 0, "%s: n_samples must be positive", who);
-    GQ_REQUIRE(!act_order || (perm && perm_inv), "%s: act_order needs perm and perm_inv buffers", who);
-    GQ_REQUIRE(max_try >= 1, "%s: max_try must be >= 1", who);
     GQ_REQUIRE((((uintptr_t)hessian | (uintptr_t)hessian_inv | (uintptr_t)workspace) & 15) == 0,
                "%s: pointers must be 16-byte aligned", who);
-    InvertWorkspace ws;
     const size_t need = carve(ws, (char *)workspace, c);
     if (workspace_bytes < need) {
         gq_set_error("%s: workspace of %zu bytes, %zu needed", who, workspace_bytes, need);
         return GQ_EWORKSPACE;
     }
-    const int64_t cp = gq_round_up(c, NB);
-    const int64_t cc = c * c;
+    return GQ_OK;
+}
 
+// scale by 2 / n, dead-diagonal fix, damping value, act-order permutation of H: everything before the tries
+int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int32_t *perm_inv, int64_t c, double n_samples,
+                   float damp_ratio, int act_order, hipStream_t stream, const char *who)
+{
+    GQ_REQUIRE(n_samples > 0, "%s: n_samples must be positive", who);
+    GQ_REQUIRE(!act_order || (perm && perm_inv), "%s: act_order needs perm and perm_inv buffers", who);
+    const int64_t cc = c * c;
     hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, c, (float)(2.0 / n_samples), ws.diag);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp, ws.fatal);
@@ -645,31 +648,38 @@ int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm
         GQ_LAUNCH_CHECK();
         GQ_HIP(hipMemcpyAsync(hessian, ws.t, (size_t)cc * 4, hipMemcpyDeviceToDevice, stream));
     }
-    GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
+    return GQ_OK;
+}
 
-    // One host round trip per try: the factor is flipped into hessian_inv on the device when the try
-    // succeeded (flip_out_kernel looks at the status word itself), and the host reads the verdict
-    // once everything has been enqueued.
-    int tries = 0;
-    while (tries < max_try) {
-        ++tries;
-        GQ_HIP(hipMemsetAsync(ws.status, 0, 256, stream));
-        GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
-        hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
-        GQ_LAUNCH_CHECK();
-        static const bool recursive = [] {   // experiments: GQ_INVERT=rec selects the recursive form
-            const char *e = getenv("GQ_INVERT");
-            return e && e[0] == 'r';
-        }();
-        int rc = recursive ? cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream)
-                           : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv, ws.status);
-        GQ_LAUNCH_CHECK();
-        int verdict[2] = {0, 0};   // status and fatal are 256 bytes apart
-        GQ_HIP(hipMemcpyAsync(&verdict[0], ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
-        GQ_HIP(hipMemcpyAsync(&verdict[1], ws.fatal, sizeof(int), hipMemcpyDeviceToHost, stream));
-        GQ_HIP(hipStreamSynchronize(stream));
+// One try, enqueued: damp the diagonal once more (in place, as the reference's loop does), factor and
+// invert a copy; the factor is flipped into hessian_inv on the device when the try succeeded
+// (flip_out_kernel looks at the status word itself).
+int invert_try(const InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_t c, hipStream_t stream)
+{
+    const int64_t cp = gq_round_up(c, NB);
+    GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
+    GQ_HIP(hipMemsetAsync(ws.status, 0, 256, stream));
+    GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
+    hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
+    GQ_LAUNCH_CHECK();
+    static const bool recursive = [] {   // experiments: GQ_INVERT=rec selects the recursive form
+        const char *e = getenv("GQ_INVERT");
+        return e && e[0] == 'r';
+    }();
+    int rc = recursive ? cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream)
+                       : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(c * c)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv, ws.status);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+// The tries after `tries` already made, one host round trip each, starting from the verdict of the last one
+// (verdict[0]: a pivot was not positive, verdict[1]: the diagonal of H is not finite).
+int invert_retry(const InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_t c, int max_try, int tries,
+                 int verdict[2], int *tries_host, hipStream_t stream, const char *who)
+{
+    for (;;) {
         if (verdict[1]) {
             if (tries_host) *tries_host = tries;
             gq_set_error("%s: the Hessian's diagonal is not finite (overflowed activations?)", who);
@@ -679,10 +689,31 @@ int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm
             if (tries_host) *tries_host = tries;
             return GQ_OK;
         }
+        if (tries >= max_try) break;
+        ++tries;
+        const int rc = invert_try(ws, hessian, hessian_inv, c, stream);
+        if (rc) return rc;
+        GQ_HIP(hipMemcpyAsync(&verdict[0], ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
+        GQ_HIP(hipMemcpyAsync(&verdict[1], ws.fatal, sizeof(int), hipMemcpyDeviceToHost, stream));
+        GQ_HIP(hipStreamSynchronize(stream));
     }
     if (tries_host) *tries_host = tries;
     gq_set_error("%s: not positive definite after %d dampings", who, tries);
     return GQ_ENOTPD;
+}
+
+int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c, double n_samples,
+                float damp_ratio, int act_order, int max_try, void *workspace, size_t workspace_bytes, int *tries_host,
+                hipStream_t stream, const char *who)
+{
+    GQ_REQUIRE(max_try >= 1, "%s: max_try must be >= 1", who);
+    InvertWorkspace ws;
+    int rc = invert_setup(ws, hessian, hessian_inv, c, workspace, workspace_bytes, who);
+    if (rc) return rc;
+    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who);
+    if (rc) return rc;
+    int verdict[2] = {1, 0};   // "not yet factored": the first pass of the loop makes try 1
+    return invert_retry(ws, hessian, hessian_inv, c, max_try, 0, verdict, tries_host, stream, who);
 }
 
 }  // namespace
@@ -693,6 +724,46 @@ extern "C" int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *pe
 {
     return invert_impl(hessian, hessian_inv, perm, perm_inv, c, n_samples, damp_ratio, act_order, max_try, workspace,
                        workspace_bytes, tries_host, (hipStream_t)stream_, "gq_hessian_invert");
+}
+
+// ---- the same call in two halves, without a host round trip in the first ------------------------
+// gq_hessian_invert_begin enqueues everything up to and including the first try and leaves its verdict
+// in device memory; the caller goes on enqueueing the work that consumes hessian_inv and reads the
+// verdict when it next has to wait for the device anyway.  gq_hessian_invert_finish takes that verdict:
+// nothing to do when the first try succeeded (the usual case: the damping makes H positive definite),
+// otherwise the remaining tries, synchronously -- what was computed from hessian_inv in between has
+// then to be computed again.
+extern "C" int gq_hessian_invert_begin(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv, int64_t c,
+                                       double n_samples, float damp_ratio, int act_order, void *workspace,
+                                       size_t workspace_bytes, int32_t *verdict_dev, gq_stream_t stream_)
+{
+    const char *who = "gq_hessian_invert_begin";
+    hipStream_t stream = (hipStream_t)stream_;
+    GQ_REQUIRE(verdict_dev, "%s: NULL verdict", who);
+    InvertWorkspace ws;
+    int rc = invert_setup(ws, hessian, hessian_inv, c, workspace, workspace_bytes, who);
+    if (rc) return rc;
+    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who);
+    if (rc) return rc;
+    rc = invert_try(ws, hessian, hessian_inv, c, stream);
+    if (rc) return rc;
+    GQ_HIP(hipMemcpyAsync(verdict_dev, ws.status, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    GQ_HIP(hipMemcpyAsync(verdict_dev + 1, ws.fatal, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    return GQ_OK;
+}
+
+extern "C" int gq_hessian_invert_finish(float *hessian, float *hessian_inv, int64_t c, int max_try, void *workspace,
+                                        size_t workspace_bytes, const int32_t *verdict_host, int *tries_host,
+                                        gq_stream_t stream_)
+{
+    const char *who = "gq_hessian_invert_finish";
+    GQ_REQUIRE(verdict_host, "%s: NULL verdict", who);
+    GQ_REQUIRE(max_try >= 1, "%s: max_try must be >= 1", who);
+    InvertWorkspace ws;
+    const int rc = invert_setup(ws, hessian, hessian_inv, c, workspace, workspace_bytes, who);
+    if (rc) return rc;
+    int verdict[2] = {verdict_host[0], verdict_host[1]};
+    return invert_retry(ws, hessian, hessian_inv, c, max_try, 1, verdict, tries_host, (hipStream_t)stream_, who);
 }
 
 // ---- the same call without any allocation -----------------------------------------------------

@@ -174,7 +174,9 @@ def quantize_llama(
         mods = [_submodule(block, nm) for nm in names]
         if world > 1:
             hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
-        hook.invert(damp_ratio=damp_ratio, act_order=act_order)
+        # no host round trip between inversion and column loops (gptq_quant_set settles it), unless a
+        # callback wants to look at the finished hook first
+        hook.invert(damp_ratio=damp_ratio, act_order=act_order, wait=on_set is not None)
         weights = [m.weight.data for m in mods]
         c = weights[0].shape[1]
         if c % group_size:
@@ -183,39 +185,52 @@ def quantize_llama(
         gb = torch.full([c // group_size], bits, dtype=torch.int32)
         if on_set is not None:
             on_set(gi, list(names), hook, weights)
+        # the column loops are enqueued and nothing is waited for: what consumes the levels on the device
+        # (gather over ranks, reconstruction or packing) is enqueued behind them, then the set is settled
+        # (metrics, verdict of the inversion); only a failed first try makes the loop run twice
         if world > 1:
             shards = [gd.row_shard(w.shape[0], rank, world) for w in weights]
             mine = [(i, w[b:e]) for i, (w, (b, e)) in enumerate(zip(weights, shards)) if e > b]   # a short Linear may leave a rank without rows
-            part = gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
-                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
-                                  save_device=device)
-            by_index = {i: res for (i, _), res in zip(mine, part)}
-            c_ = weights[0].shape[1]
-            fields = {"qscale": None, "sscale": None, "scale_bit_width": None if sbw is None else sbw.to(torch.uint8).to(device),
-                      "perm_inv": (hook.perm_inv.to(torch.int16) if hook.perm_inv is not None
-                                   else torch.arange(c_, dtype=torch.int16, device=device)),
-                      "group_sizes": gs.to(dtype=torch.int16, device=device),
-                      "group_bit_widths": gb.to(dtype=torch.uint8, device=device)}
-            outs = [gd.gather_quant_result(by_index.get(i), fields, w.shape[0], c_, w.dtype, device)
-                    for i, w in enumerate(weights)]
         else:
-            outs = gptq_quant_set(weights, hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
-                                  gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
-                                  save_device=device)
-        for name, mod, res in zip(names, mods, outs):
-            canonical = f"model.layers.{gi}.{name}"
-            meta = res["quant_meta"]
-            results["metrics"][canonical] = res["metrics"]
-            results["data"][canonical] = _to_device(meta, torch.device("cpu"))
-            parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
-            if pack:
-                layer = QuantLinear.from_quant_meta(meta, device, validate=False, has_perm=bool(act_order))
-            elif mod.bias is None:
-                # the dense reconstructed weight the reference leaves in the model, in an nn.Linear whose
-                # forward (the replay of the calibration batches) runs this library's dense MFMA kernel
-                layer = HipLinear.from_weight(reconstruct_weight(meta, dtype, device))
+            mine = list(enumerate(weights))
+        part = gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
+                              gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
+                              save_device=device, wait=False)
+        if world > 1:
+            part.settle()   # the gather over ranks combines the shards' metrics: they have to be there
+        while True:
+            if world > 1:
+                by_index = {i: res for (i, _), res in zip(mine, part)}
+                c_ = weights[0].shape[1]
+                fields = {"qscale": None, "sscale": None, "scale_bit_width": None if sbw is None else sbw.to(torch.uint8).to(device),
+                          "perm_inv": (hook.perm_inv.to(torch.int16) if hook.perm_inv is not None
+                                       else torch.arange(c_, dtype=torch.int16, device=device)),
+                          "group_sizes": gs.to(dtype=torch.int16, device=device),
+                          "group_bit_widths": gb.to(dtype=torch.uint8, device=device)}
+                outs = [gd.gather_quant_result(by_index.get(i), fields, w.shape[0], c_, w.dtype, device)
+                        for i, w in enumerate(weights)]
             else:
-                mod.weight.data = reconstruct_weight(meta, dtype, device)
+                outs = list(part)
+            layers = []
+            for mod, res in zip(mods, outs):
+                meta = res["quant_meta"]
+                if pack:
+                    layers.append(QuantLinear.from_quant_meta(meta, device, validate=False, has_perm=bool(act_order)))
+                elif mod.bias is None:
+                    # the dense reconstructed weight the reference leaves in the model, in an nn.Linear whose
+                    # forward (the replay of the calibration batches) runs this library's dense MFMA kernel
+                    layers.append(HipLinear.from_weight(reconstruct_weight(meta, dtype, device)))
+                else:
+                    layers.append(reconstruct_weight(meta, dtype, device))
+            if part.settle():
+                break
+        for name, mod, res, layer in zip(names, mods, outs, layers):
+            canonical = f"model.layers.{gi}.{name}"
+            results["metrics"][canonical] = res["metrics"]
+            results["data"][canonical] = _to_device(res["quant_meta"], torch.device("cpu"))
+            parent = _submodule(block, name.rsplit(".", 1)[0]) if "." in name else block
+            if isinstance(layer, torch.Tensor):
+                mod.weight.data = layer
                 layer = mod
             setattr(parent, name.rsplit(".", 1)[-1], layer)
 

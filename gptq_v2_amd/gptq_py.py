@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .quant import _group_list
+from .quant import _group_list, with_host_list
 
 
 class HessianHook:
@@ -33,6 +33,7 @@ class HessianHook:
         self.perm: Optional[torch.Tensor] = None
         self.perm_inv: Optional[torch.Tensor] = None
         self.tries: int = 0
+        self._pending = None   # ops.PendingInversion of invert(wait=False) until confirm() has looked at it
 
     @property
     def hessian(self) -> Optional[torch.Tensor]:
@@ -81,17 +82,40 @@ class HessianHook:
             ops.xtx_accumulate(self._hessian, x, save_lower_only=False, compute_lower_only=True)
 
     @torch.no_grad()
-    def invert(self, damp_ratio: float = 1e-2, act_order: bool = True) -> torch.Tensor:
+    def invert(self, damp_ratio: float = 1e-2, act_order: bool = True, wait: bool = True) -> torch.Tensor:
         """gptq_py.py:38-66.  Leaves ``hessian`` scaled, permuted and damped, sets ``perm`` /
-        ``perm_inv`` (int64, as torch.argsort returns them) and returns ``hessian_inv``."""
-        u, perm, perm_inv, tries = ops.hessian_invert(self.hessian, float(self.n_samples), damp_ratio, act_order,
-                                                      max_try=100)
+        ``perm_inv`` (int64, as torch.argsort returns them) and returns ``hessian_inv``.
+
+        The reference's retry loop looks at every try's result on the host (gptq_py.py:62).  With
+        ``wait=False`` only the first try is enqueued and nothing is waited for: the host goes on
+        enqueueing the work that reads ``hessian_inv`` while the device inverts, and ``confirm()`` -- which
+        ``gptq_quant_set`` calls when it fetches its metrics -- reads the verdict; if the damped Hessian
+        was not positive definite after all, it makes the remaining tries and the caller redoes what it
+        had computed from ``hessian_inv``."""
+        if wait:
+            u, perm, perm_inv, tries = ops.hessian_invert(self.hessian, float(self.n_samples), damp_ratio, act_order,
+                                                          max_try=100)
+        else:
+            self._pending = ops.hessian_invert_begin(self.hessian, float(self.n_samples), damp_ratio, act_order)
+            u, perm, perm_inv, tries = self._pending.u, self._pending.perm, self._pending.perm_inv, 1
         self.hessian_inv = u
         self.tries = tries
         if act_order:
             self.perm = perm.to(torch.int64)
             self.perm_inv = perm_inv.to(torch.int64)
         return self.hessian_inv
+
+    @torch.no_grad()
+    def confirm(self) -> bool:
+        """Settles ``invert(wait=False)``: waits for the device, and if the first try had failed makes the
+        remaining ones (``hessian_inv`` is rewritten in place, ``tries`` updated).  Returns False in that case
+        -- whatever was computed from ``hessian_inv`` since is void -- and True otherwise (also when nothing
+        was pending)."""
+        if self._pending is None:
+            return True
+        pending, self._pending = self._pending, None
+        self.tries = ops.hessian_invert_finish(pending, max_try=100)
+        return self.tries == 1
 
 
 # The Linears that share a Hessian are independent given U (and so are the rows of one Linear).
@@ -138,7 +162,7 @@ def _const_tensor(values, dtype: torch.dtype, device) -> torch.Tensor:
         if len(_const_cache) > 256:
             _const_cache.clear()
         t = _const_cache[key] = torch.as_tensor(list(values), dtype=dtype, device=device)
-    return t.clone()
+    return with_host_list(t.clone(), values)
 
 
 @torch.no_grad()
@@ -157,11 +181,17 @@ def gptq_quant_set(
         quant_norm: float = 2.4,
         quant_use_kernel: bool = False,
         save_device: torch.device = torch.device('cpu'),
+        wait: bool = True,
 ) -> list:
     """``gptq_quant`` for every weight of ``weights`` against ONE Hessian -- the Linears of an
     input-sharing set, which the reference quantises one after the other (llama.py:150-170).
     Same arguments and, per weight, the same result dictionary as ``gptq_quant``; the work of all
-    of them is enqueued on side streams before anything is waited for."""
+    of them is enqueued on side streams before anything is waited for.
+
+    ``wait=False`` returns as soon as everything is enqueued: a ``QuantSetResult`` whose ``quant_meta``
+    tensors are valid in stream order and whose ``metrics`` are None until ``settle()`` has fetched them.
+    The caller enqueues what consumes the levels (reconstruction, packing, the replay of the
+    calibration batches) and settles afterwards, so the device never waits for the host."""
     if quant_mse and quant_use_kernel:
         raise NotImplementedError("quant_use_kernel=True calls exllamav2_ext, which the reference does not import "
                                   "either (quant.py:4)")
@@ -194,89 +224,141 @@ def gptq_quant_set(
 
     main = torch.cuda.current_stream(device)
     side = _side_streams(device)
-    for st in side:
-        st.wait_stream(main)   # inputs were produced on the caller's stream; earlier results of ours were read there
     per_weight = 1 if scale_bits > 0 else ROW_SLICES   # the step of a group's scale grid is a maximum over all rows
-    jobs = []   # (weight index, row range, result tensors, metric sums)
-    k = 0
-    for wi, weight in enumerate(weights):
-        w = weight if weight.is_contiguous() else weight.contiguous()
-        if w.shape[0] % 4:
-            # the trailing-update GEMMs work on multiples of 4 rows: pad with zero rows (rows are
-            # independent; a zero row quantises to zero error and is cut off again below)
-            w = torch.cat([w, w.new_zeros(4 - w.shape[0] % 4, w.shape[1])], dim=0)
-        for b, e in _row_slices(w.shape[0], per_weight):
-            with torch.cuda.stream(side[k % len(side)]):
-                res = ops.quantize_layer(w[b:e], perm32, u, gs, gb, sym=quant_symmetric, semantics=sem,
-                                         want_quant=True, want_error=hessian_hook is not None, block_sizes=blocks,
-                                         scale_bits=scale_bits, shrink=shrink, norm=quant_norm)
-                sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"])
-            jobs.append((wi, res, sums))
-            k += 1
-    for st in side:
-        main.wait_stream(st)
 
-    out = []
-    # one device-to-host round trip for the metric sums of the whole set, one conversion of perm_inv
-    all_sums = torch.stack([j[2] for j in jobs]).tolist()
-    perm_inv_set = hessian_hook.perm_inv.to(torch.int16) if perm32 is not None else None
-    for wi, weight in enumerate(weights):
-        mine = [j for j in jobs if j[0] == wi]
-        n_rows, n_columns = weight.shape
-        dtype = weight.dtype
-        cat = (lambda name: mine[0][1][name][:n_rows]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0)[:n_rows])
-        sums = [sum(all_sums[k][i] for k, j in enumerate(jobs) if j[0] == wi) for i in range(4)]
-        n = float(n_rows * n_columns)
-        gptq_error = sums[0] / n
-        metrics = {
-            "gptq_error": gptq_error,
-            "gptq_norm": sums[1] / n if hessian_hook is not None else gptq_error,
-            "l2.0_error": sums[2] / n,
-            # the reference takes this mean in the weight's 16-bit dtype (gptq_py.py:237)
-            "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(dtype).item(),
-        }
-        if perm32 is not None:
-            perm_inv = perm_inv_set
-        else:
-            perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
-        qweight, scale, qzero = cat("qweight"), cat("scale"), cat("qzero")
-        qscale = sscale = sbw = None
-        out_gs, out_gb = list(gs), list(gb)
-        if scale_bit_width is not None:
-            # gptq_py.py:202-229: with scale quantisation the groups are stored widest first (bit width,
-            # then size, descending; earlier groups first among equals) and the column order follows
-            order = sorted(range(len(gs)), key=lambda g: (gb[g], gs[g], -g), reverse=True)
-            sbw = torch.as_tensor(scale_bit_width).to(dtype=torch.uint8, device=save_device)
-            if scale_bits > 0:
-                qscale, sscale = cat("qscale"), mine[0][1]["sscale"]
-            if order != list(range(len(gs))):
-                starts = [0]
-                for v in gs:
-                    starts.append(starts[-1] + v)
-                idx_g = torch.tensor(order, dtype=torch.int64, device=device)
-                idx_c = torch.cat([torch.arange(starts[g], starts[g + 1], device=device) for g in order])
-                qweight, scale, qzero = qweight[:, idx_c], scale[:, idx_g], qzero[:, idx_g]
-                if qscale is not None:
-                    qscale, sscale = qscale[:, idx_g], sscale[idx_g]
-                perm = hessian_hook.perm if perm32 is not None else torch.arange(n_columns, device=device)
-                stored = perm[idx_c]   # stored column j holds original column stored[j]
-                perm_inv = torch.empty(n_columns, dtype=torch.int64, device=device)
-                perm_inv[stored] = torch.arange(n_columns, device=device)
-                perm_inv = perm_inv.to(torch.int16)
-                out_gs, out_gb = [gs[g] for g in order], [gb[g] for g in order]
-        quant_meta = {
-            "qweight": qweight.to(device=save_device),
-            "scale": scale.to(device=save_device),
-            "qzero": qzero.to(device=save_device),
-            "qscale": None if qscale is None else qscale.to(device=save_device),
-            "sscale": None if sscale is None else sscale.to(device=save_device),
-            "perm_inv": perm_inv.to(device=save_device),
-            "group_sizes": _const_tensor(out_gs, torch.int16, save_device),
-            "group_bit_widths": _const_tensor(out_gb, torch.uint8, save_device),
-            "scale_bit_width": sbw,
-        }
-        out.append({"quant_meta": quant_meta, "metrics": metrics})
-    return out
+    def enqueue():
+        for st in side:
+            st.wait_stream(main)   # inputs were produced on the caller's stream; earlier results of ours were read there
+        jobs = []   # (weight index, row range, result tensors, metric sums)
+        k = 0
+        for wi, weight in enumerate(weights):
+            w = weight if weight.is_contiguous() else weight.contiguous()
+            if w.shape[0] % 4:
+                # the trailing-update GEMMs work on multiples of 4 rows: pad with zero rows (rows are
+                # independent; a zero row quantises to zero error and is cut off again below)
+                w = torch.cat([w, w.new_zeros(4 - w.shape[0] % 4, w.shape[1])], dim=0)
+            for b, e in _row_slices(w.shape[0], per_weight):
+                with torch.cuda.stream(side[k % len(side)]):
+                    res = ops.quantize_layer(w[b:e], perm32, u, gs, gb, sym=quant_symmetric, semantics=sem,
+                                             want_quant=True, want_error=hessian_hook is not None, block_sizes=blocks,
+                                             scale_bits=scale_bits, shrink=shrink, norm=quant_norm)
+                    sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"])
+                jobs.append((wi, res, sums))
+                k += 1
+        for st in side:
+            main.wait_stream(st)
+
+        # the result dictionaries first -- device work only, enqueued behind the column loops while those
+        # still run -- and then the one wait of the call
+        perm_inv_set = hessian_hook.perm_inv.to(torch.int16) if perm32 is not None else None
+        metas = []
+        for wi, weight in enumerate(weights):
+            mine = [j for j in jobs if j[0] == wi]
+            n_rows, n_columns = weight.shape
+            cat = (lambda name: mine[0][1][name][:n_rows]) if len(mine) == 1 else (lambda name: torch.cat([j[1][name] for j in mine], dim=0)[:n_rows])
+            if perm32 is not None:
+                perm_inv = perm_inv_set
+            else:
+                perm_inv = torch.arange(n_columns, dtype=torch.int16, device=device)
+            qweight, scale, qzero = cat("qweight"), cat("scale"), cat("qzero")
+            qscale = sscale = sbw = None
+            out_gs, out_gb = list(gs), list(gb)
+            if scale_bit_width is not None:
+                # gptq_py.py:202-229: with scale quantisation the groups are stored widest first (bit width,
+                # then size, descending; earlier groups first among equals) and the column order follows
+                order = sorted(range(len(gs)), key=lambda g: (gb[g], gs[g], -g), reverse=True)
+                sbw = torch.as_tensor(scale_bit_width).to(dtype=torch.uint8, device=save_device)
+                if scale_bits > 0:
+                    qscale, sscale = cat("qscale"), mine[0][1]["sscale"]
+                if order != list(range(len(gs))):
+                    starts = [0]
+                    for v in gs:
+                        starts.append(starts[-1] + v)
+                    idx_g = torch.tensor(order, dtype=torch.int64, device=device)
+                    idx_c = torch.cat([torch.arange(starts[g], starts[g + 1], device=device) for g in order])
+                    qweight, scale, qzero = qweight[:, idx_c], scale[:, idx_g], qzero[:, idx_g]
+                    if qscale is not None:
+                        qscale, sscale = qscale[:, idx_g], sscale[idx_g]
+                    perm = hessian_hook.perm if perm32 is not None else torch.arange(n_columns, device=device)
+                    stored = perm[idx_c]   # stored column j holds original column stored[j]
+                    perm_inv = torch.empty(n_columns, dtype=torch.int64, device=device)
+                    perm_inv[stored] = torch.arange(n_columns, device=device)
+                    perm_inv = perm_inv.to(torch.int16)
+                    out_gs, out_gb = [gs[g] for g in order], [gb[g] for g in order]
+            metas.append({
+                "qweight": qweight.to(device=save_device),
+                "scale": scale.to(device=save_device),
+                "qzero": qzero.to(device=save_device),
+                "qscale": None if qscale is None else qscale.to(device=save_device),
+                "sscale": None if sscale is None else sscale.to(device=save_device),
+                "perm_inv": perm_inv.to(device=save_device),
+                "group_sizes": _const_tensor(out_gs, torch.int16, save_device),
+                "group_bit_widths": _const_tensor(out_gb, torch.uint8, save_device),
+                "scale_bit_width": sbw,
+            })
+        return jobs, metas
+
+    def finish(jobs, metas, all_sums):
+        out = []
+        for wi, weight in enumerate(weights):
+            n_rows, n_columns = weight.shape
+            sums = [sum(all_sums[k][i] for k, j in enumerate(jobs) if j[0] == wi) for i in range(4)]
+            n = float(n_rows * n_columns)
+            gptq_error = sums[0] / n
+            metrics = {
+                "gptq_error": gptq_error,
+                "gptq_norm": sums[1] / n if hessian_hook is not None else gptq_error,
+                "l2.0_error": sums[2] / n,
+                # the reference takes this mean in the weight's 16-bit dtype (gptq_py.py:237)
+                "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(weight.dtype).item(),
+            }
+            out.append({"quant_meta": metas[wi], "metrics": metrics})
+        return out
+
+    def run_to_the_end():
+        # one device-to-host round trip for the metric sums of the whole set; the same wait settles an
+        # inversion that was enqueued without one (if it needed another damping, U has just been written
+        # again and the set is quantised once more from it)
+        while True:
+            jobs, metas = enqueue()
+            all_sums = torch.stack([j[2] for j in jobs]).tolist()
+            if hessian_hook is None or hessian_hook.confirm():
+                return finish(jobs, metas, all_sums)
+
+    if wait:
+        return run_to_the_end()
+    jobs, metas = enqueue()
+    sums_dev = torch.stack([j[2] for j in jobs])
+
+    def settle_now():
+        all_sums = sums_dev.tolist()
+        if hessian_hook is None or hessian_hook.confirm():
+            return finish(jobs, metas, all_sums), True
+        return run_to_the_end(), False
+
+    return QuantSetResult([{"quant_meta": m, "metrics": None} for m in metas], settle_now)
+
+
+class QuantSetResult(list):
+    """What ``gptq_quant_set(wait=False)`` returns: the per-weight result dictionaries, with ``metrics``
+    still None and the tensors of ``quant_meta`` valid in stream order."""
+
+    def __init__(self, items, settle_now) -> None:
+        super().__init__(items)
+        self._settle_now = settle_now
+
+    def settle(self) -> bool:
+        """Waits for the device and fills in ``metrics``.  Returns False if the inversion behind the set had
+        been enqueued without a wait (``HessianHook.invert(wait=False)``) and its first try turned out to have
+        failed: the set has then been quantised again from the final U, every ``quant_meta`` here has been
+        replaced, and whatever the caller derived from the old ones has to be derived again."""
+        if self._settle_now is None:
+            return True
+        final, first_try_held = self._settle_now()
+        self._settle_now = None
+        for mine, res in zip(self, final):
+            mine.update(res)
+        return first_try_held
 
 
 @torch.no_grad()
@@ -336,7 +418,7 @@ class GPTQ:
         group_sizes = torch.full([c // gsz], gsz, dtype=torch.int32)
         group_bits = torch.full([c // gsz], bits, dtype=torch.int32)
         blocks = [blocksize] * (c // blocksize) + ([c % blocksize] if c % blocksize else [])
-        self.hook.invert(damp_ratio=percdamp, act_order=actorder)
+        self.hook.invert(damp_ratio=percdamp, act_order=actorder, wait=False)   # settled inside gptq_quant
         return gptq_quant(w, self.hook, group_sizes, group_bits, gptq_use_kernel=static_groups,
                           gptq_block_sizes=torch.tensor(blocks, dtype=torch.int32), quant_symmetric=sym, quant_mse=False,
                           save_device=save_device if save_device is not None else w.device)

@@ -142,6 +142,53 @@ def hessian_invert(hessian: torch.Tensor, n_samples: float, damp_ratio: float = 
     return u, perm, perm_inv, tries.value
 
 
+class PendingInversion:
+    """What ``hessian_invert_begin`` leaves behind: the outputs (valid in stream order if the first try
+    succeeds), the verdict of that try in device memory and the workspace ``hessian_invert_finish`` needs."""
+
+    def __init__(self, hessian, u, perm, perm_inv, workspace, verdict):
+        self.hessian, self.u, self.perm, self.perm_inv = hessian, u, perm, perm_inv
+        self.workspace, self.verdict = workspace, verdict
+
+
+def hessian_invert_begin(hessian: torch.Tensor, n_samples: float, damp_ratio: float = 1e-2,
+                         act_order: bool = True) -> PendingInversion:
+    """``hessian_invert`` up to and including its first try, without waiting for the device."""
+    _check(hessian, "hessian", torch.float32, 2)
+    c = hessian.shape[0]
+    if hessian.shape != (c, c):
+        raise ValueError("hessian must be square")
+    dev = hessian.device
+    lib = _lib.load()
+    u = torch.empty_like(hessian)
+    perm = torch.empty(c, dtype=torch.int32, device=dev) if act_order else None
+    perm_inv = torch.empty(c, dtype=torch.int32, device=dev) if act_order else None
+    ws_bytes = lib.gq_hessian_invert_workspace(c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    verdict = torch.empty(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gq_hessian_invert_begin(_p(hessian), _p(u), _p(perm), _p(perm_inv), c, float(n_samples),
+                                         float(damp_ratio), int(act_order), _p(ws), ws_bytes, _p(verdict),
+                                         _stream(hessian))
+    _lib.check(rc, "gq_hessian_invert_begin")
+    return PendingInversion(hessian, u, perm, perm_inv, ws, verdict)
+
+
+def hessian_invert_finish(pending: PendingInversion, max_try: int = 100) -> int:
+    """Reads the verdict of the first try (waits for the device) and makes the remaining tries if it
+    failed.  Returns the number of tries; more than 1 means ``pending.u`` was written again and whatever
+    was computed from it in between is void."""
+    v = pending.verdict.tolist()
+    verdict = (ctypes.c_int32 * 2)(int(v[0]), int(v[1]))
+    tries = ctypes.c_int(0)
+    h = pending.hessian
+    with torch.cuda.device(h.device):
+        rc = _lib.load().gq_hessian_invert_finish(_p(h), _p(pending.u), h.shape[0], int(max_try), _p(pending.workspace),
+                                                  pending.workspace.numel(), verdict, ctypes.byref(tries), _stream(h))
+    _lib.check(rc, "gq_hessian_invert_finish")
+    return tries.value
+
+
 def find_params(weights_t: torch.Tensor, col0: int, ncols: int, bits: int, sym: bool = False):
     """weights_t (C, R) fp32 -> scale (R,), qzero (R,) fp32 over columns [col0, col0+ncols)."""
     _check(weights_t, "weights_t", torch.float32, 2)

@@ -143,7 +143,18 @@ def collate_quantizers(*args) -> dict:
 
 
 def _group_list(group_sizes) -> list:
-    return [int(v) for v in (group_sizes.tolist() if isinstance(group_sizes, torch.Tensor) else group_sizes)]
+    """Group sizes / bit widths as Python ints.  A tensor that ``with_host_list`` has tagged brings its values
+    along, so a result dictionary kept on the GPU can be consumed without a device-to-host round trip."""
+    if isinstance(group_sizes, torch.Tensor):
+        host = getattr(group_sizes, "_host_list", None)
+        return list(host) if host is not None else [int(v) for v in group_sizes.tolist()]
+    return [int(v) for v in group_sizes]
+
+
+def with_host_list(t: torch.Tensor, values) -> torch.Tensor:
+    """Tags a small constant tensor with the Python values it was built from (see ``_group_list``)."""
+    t._host_list = tuple(int(v) for v in values)
+    return t
 
 
 def construct_matrix(qweight: torch.Tensor, scale: torch.Tensor, qzero: torch.Tensor,

@@ -101,6 +101,27 @@ int gq_hessian_invert(float *hessian, float *hessian_inv, int32_t *perm, int32_t
                       int64_t c, double n_samples, float damp_ratio, int act_order, int max_try,
                       void *workspace, size_t workspace_bytes, int *tries_host, gq_stream_t stream);
 
+/* gq_hessian_invert in two halves, so that the host does not wait for the device between the
+ * inversion and the work that consumes it.
+ * gq_hessian_invert_begin enqueues everything up to and including the first try (same arguments and
+ * same effect on hessian / hessian_inv / perm / perm_inv as gq_hessian_invert with max_try = 1) and
+ * leaves the verdict of that try in device memory: verdict_dev[0] != 0: a pivot was not positive (one
+ * more damping is needed), verdict_dev[1] != 0: the diagonal of H is not finite.  It does not
+ * synchronise.  hessian_inv is written only if the try succeeded; the caller may enqueue work that
+ * reads it at once and must discard that work's results if the verdict turns out bad.
+ * gq_hessian_invert_finish takes the verdict as read back by the caller (verdict_host[2], host memory;
+ * the workspace must be the one given to _begin, untouched) and returns at once with *tries_host = 1
+ * if the first try succeeded; otherwise it makes the remaining tries (up to max_try in all) the way
+ * gq_hessian_invert does, one host round trip each.  begin + finish leave exactly what gq_hessian_invert
+ * leaves, bit for bit.
+ * ref: gptq_py.py:55-66 (the retry loop, whose test of the result forces a host round trip per try). */
+int gq_hessian_invert_begin(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm_inv,
+                            int64_t c, double n_samples, float damp_ratio, int act_order,
+                            void *workspace, size_t workspace_bytes, int32_t *verdict_dev, gq_stream_t stream);
+int gq_hessian_invert_finish(float *hessian, float *hessian_inv, int64_t c, int max_try,
+                             void *workspace, size_t workspace_bytes, const int32_t *verdict_host,
+                             int *tries_host, gq_stream_t stream);
+
 /* gq_hessian_invert without a workspace argument and without any allocation: the workspace is a
  * device array built into the library (about 12.6 MB on every GPU the library runs on, held until
  * the process ends), so C is limited to gq_hessian_invert_static_max_c() = 1024 (larger C:

@@ -153,6 +153,103 @@ def test_invert_retries_until_positive_definite(amd, oracle, gpu):
     assert resid.abs().max() < 1e-2
 
 
+def _indefinite_hessian(c=256, seed=5):
+    """Symmetric H with one negative eigenvalue that needs a few dampings of 0.01 * mean(diag)."""
+    gen = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(c, c, generator=gen, dtype=torch.float64))
+    ev = torch.linspace(1.0, 2.0, c, dtype=torch.float64)
+    ev[0] = -2.5 * 0.01 * 1.5
+    h = (q * ev) @ q.t()
+    return 0.5 * (h + h.t())
+
+
+@pytest.mark.parametrize("act_order", [False, True])
+def test_invert_without_wait_equals_invert(amd, gpu, act_order):
+    """invert(wait=False) + confirm() leaves what invert() leaves, bit for bit: on a Hessian whose first
+    try succeeds (confirm() -> True, nothing redone) and on one that needs more dampings
+    (confirm() -> False after the remaining tries)."""
+    gen = torch.Generator(device=gpu).manual_seed(11)
+    x = (torch.randn(2048, 384, generator=gen, device=gpu) * (1 + 3 * torch.arange(384, device=gpu) / 384)).half()
+    good = torch.zeros(384, 384, device=gpu)
+    amd.ops.xtx_accumulate(good, x)
+    bad = (_indefinite_hessian() * 0.5).float().to(gpu)
+    for h0, first_try_ok in ((good, True), (bad, False)):
+        a, b = amd.HessianHook(), amd.HessianHook()
+        a.hessian, b.hessian = h0.clone(), h0.clone()
+        a.n_samples = b.n_samples = 1
+        ua = a.invert(damp_ratio=0.01, act_order=act_order)
+        ub = b.invert(damp_ratio=0.01, act_order=act_order, wait=False)
+        assert b.confirm() is first_try_ok
+        assert b.confirm() is True   # nothing pending any more
+        assert a.tries == b.tries and (a.tries == 1) == first_try_ok
+        assert torch.equal(ua, ub) and torch.equal(a.hessian, b.hessian)
+        if act_order:
+            assert torch.equal(a.perm, b.perm) and torch.equal(a.perm_inv, b.perm_inv)
+
+
+def test_quant_set_redoes_the_set_when_the_first_try_failed(amd, gpu):
+    """gptq_quant_set on a hook inverted without a wait: when the verdict read with the metrics says the
+    first try failed, the set is quantised again from the final U -- same result as the synchronous order."""
+    h0 = (_indefinite_hessian() * 0.5).float().to(gpu)
+    gen = torch.Generator(device=gpu).manual_seed(3)
+    ws = [(torch.randn(r, 256, generator=gen, device=gpu) * 0.02).half() for r in (64, 128)]
+    gs = torch.full([2], 128, dtype=torch.int32)
+    gb = torch.full([2], 4, dtype=torch.int32)
+    outs = []
+    for wait in (True, False):
+        hook = amd.HessianHook()
+        hook.hessian, hook.n_samples = h0.clone(), 1
+        hook.invert(damp_ratio=0.01, act_order=True, wait=wait)
+        outs.append(amd.gptq_quant_set(ws, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False,
+                                       save_device=gpu))
+        assert hook.tries >= 3 and hook._pending is None
+    for ra, rb in zip(*outs):
+        for k, v in ra["quant_meta"].items():
+            assert (v is None and rb["quant_meta"][k] is None) or torch.equal(v, rb["quant_meta"][k]), k
+        for k, v in ra["metrics"].items():   # double sums accumulated by atomics: equal up to their order
+            assert abs(v - rb["metrics"][k]) <= 1e-12 * abs(v), k
+
+
+@pytest.mark.parametrize("first_try_holds", [True, False])
+def test_quant_set_without_wait_settles_to_the_same_result(amd, gpu, first_try_holds):
+    """gptq_quant_set(wait=False): metrics are None until settle(); settle() says whether the levels handed
+    out at once were final (True) or have been replaced after the inversion needed more dampings (False);
+    either way the settled result equals the synchronous one."""
+    c = 256
+    if first_try_holds:
+        gen = torch.Generator(device=gpu).manual_seed(21)
+        x = (torch.randn(1024, c, generator=gen, device=gpu) * (1 + 3 * torch.arange(c, device=gpu) / c)).half()
+        h0 = torch.zeros(c, c, device=gpu)
+        amd.ops.xtx_accumulate(h0, x)
+    else:
+        h0 = (_indefinite_hessian(c) * 0.5).float().to(gpu)
+    gen = torch.Generator(device=gpu).manual_seed(4)
+    ws = [(torch.randn(r, c, generator=gen, device=gpu) * 0.02).half() for r in (64, 192)]
+    gs = torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.full([c // 128], 4, dtype=torch.int32)
+    ref_hook = amd.HessianHook()
+    ref_hook.hessian, ref_hook.n_samples = h0.clone(), 1
+    ref_hook.invert()
+    ref = amd.gptq_quant_set(ws, ref_hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu)
+    hook = amd.HessianHook()
+    hook.hessian, hook.n_samples = h0.clone(), 1
+    hook.invert(wait=False)
+    part = amd.gptq_quant_set(ws, hook, gs, gb, gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu,
+                              wait=False)
+    assert all(r["metrics"] is None for r in part)
+    early = [r["quant_meta"]["qweight"] for r in part]
+    assert part.settle() is first_try_holds
+    assert part.settle() is True
+    assert hook.tries == ref_hook.tries
+    for ra, rb, q0 in zip(ref, part, early):
+        for k, v in ra["quant_meta"].items():
+            assert (v is None and rb["quant_meta"][k] is None) or torch.equal(v, rb["quant_meta"][k]), k
+        if first_try_holds:
+            assert rb["quant_meta"]["qweight"] is q0   # what was handed out at once is what stays
+        for k, v in ra["metrics"].items():
+            assert abs(v - rb["metrics"][k]) <= 1e-12 * abs(v), k
+
+
 def test_invert_llama_size(amd, oracle, gpu):
     """C = 4096 (recursion depth 5) and C = 768 (6 leaves, uneven splits): U^T U H = I."""
     for c, n in ((768, 4096), (4096, 8192)):
