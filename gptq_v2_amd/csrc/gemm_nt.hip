@@ -47,6 +47,13 @@
 // draws, not their latency.  (6.3 GB are fetched past the L2 per 12288-row launch with bands of 2 and
 // the library's tile order fetches 36 % less, but bands of 4 or 8 with the stagger, which fetch a third
 // less too, change nothing measurable, in isolation or inside the whole quantisation step.)
+// The same switches on this kernel (back-to-back 12288 x 4096 / 4096 x 11008 launches, results wrong of
+// course): without any of the waits -- all four lgkmcnt(0), the vmcnt(0), the barrier -- 1220-1225 /
+// 1295-1318 TFLOP/s against 1224 / 1300 as built: synchronisation costs nothing measurable.  Without the DMA
+// issue 1441 / 1580, without the fragment reads 1472 / 1495, with neither 1738 / 1876 (the operands then
+// never change, which also lowers the power of the MFMAs themselves).  What the kernel pays for is moving
+// bytes -- 64 KiB per k-step into the LDS and 96 KiB out of it per CU -- under one power budget with the
+// matrix pipe, not waiting for them.
 // Cycle stamps per phase of a k-step (one wave of each SIMD pair, 12288 x 4096): the two waves of a SIMD do
 // not alternate.  After the barrier the older wave (0-3) wins the matrix pipe whenever it is ready, runs
 // its next three quarters nearly alone and then waits ~780 of the step's ~2300 cycles at the barrier,
