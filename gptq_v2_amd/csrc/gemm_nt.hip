@@ -52,7 +52,7 @@
 // 1295-1318 TFLOP/s against 1224 / 1300 as built: synchronisation costs nothing measurable.  Without the DMA
 // issue 1441 / 1580, without the fragment reads 1472 / 1495, with neither 1738 / 1876 (the operands then
 // never change, which also lowers the power of the MFMAs themselves).  What the kernel pays for is moving
-// bytes -- 64 KiB per k-step into the LDS and 96 KiB out of it per CU -- under one power budget with the
+// bytes -- 64 KiB per k-step into the LDS and 192 KiB out of it per CU (24 fragment reads of 1 KiB per wave) -- under one power budget with the
 // matrix pipe, not waiting for them.
 // Cycle stamps per phase of a k-step (one wave of each SIMD pair, 12288 x 4096): the two waves of a SIMD do
 // not alternate.  After the barrier the older wave (0-3) wins the matrix pipe whenever it is ready, runs
