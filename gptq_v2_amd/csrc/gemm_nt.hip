@@ -61,6 +61,20 @@
 // and arrives last.  Issuing all eight DMA pieces of a step in one quarter instead of four in each of
 // two costs 5-6 %; reading the eight fragments of the two wide quarters back to back instead of one
 // per two MFMAs gains 0.4-0.8 % (within box noise, not kept).
+// The four-wave kernel again, as a stream with buffer-load DMA: with one asm statement per MFMA and the hooks of
+// this kernel it ran 12 % behind (1131 against 1283 TFLOP/s at 12288 x 4096) -- one wave per SIMD issues one
+// instruction per four cycles, so a 16-cycle MFMA leaves three slots, and hipcc's s_nop behind every asm
+// statement, a fragment read and the three instructions of a DMA piece overran them.  With at most two
+// instructions behind any MFMA (the DMA piece split over three MFMAs: scalar offset, M0, load) it reached this
+// kernel's speed, not more: 1310-1314 / 1326-1347 / 1346-1349 / 1366 against 1299-1304 / 1344-1346 / 1348-1351
+// / 1377-1379 on the four shapes.  Cycle stamps around its waits: lgkmcnt 40 cycles (the stamp's own latency),
+// vmcnt 9, barrier 28 -- nothing is waited for -- while the 64 MFMAs of a chunk take 1390-1545 cycles, 22-24
+// per MFMA where an unthrottled pipe takes 16 (tools/src/mfma_rate.hip: 1950-2150 TFLOP/s on operands that
+// never change).  The limiter holds back MFMA issue itself; SQ_WAIT_ANY is 0.25-0.29 of the wave cycles in
+// both kernels and 0.05 in the library's, whose pipe occupancy times clock is 8-10 % higher on every shape.
+// What makes its flops cheaper was not found: not the LDS bytes (equal in the four-wave kernel), not the tile
+// order (bands of 1 fetch 2.4 x as much past the L2 as bands of 3 and cost 5 %, so its 36 % less is worth
+// about 1 %), not the operand order of consecutive MFMAs (holding src0 instead of src1 fixed: -0.7 %).
 // (For such experiments: accumulators bound to inline-asm MFMAs as C++ variables are moved between
 // registers by hipcc, which does not know that the asm is a matrix instruction still in flight, and
 // come out wrong; through the builtin every result gets a register of its own and three moves per
