@@ -246,6 +246,17 @@ def serving(torch, amd, sets, bits, dev):
             del meta
     out = {"weight_bits_in_memory": 3 if bits == 3 else 4,
            "packed_weight_bytes_per_block": int(sum(layer.qweight.numel() * 4 for _, _, layer in layers))}
+    fused = None
+    if len(sets) == 4 and len(sets[0][1]) == 3 and len(sets[2][1]) == 2:   # the Llama block: q/k/v, o, gate/up, down
+        # the parts of a concatenation share one act-order (they are quantised against one Hessian)
+        by_set, at = [], 0
+        for c, outs in sets:
+            by_set.append([layer for _, _, layer in layers[at:at + len(outs)]])
+            at += len(outs)
+        for group in by_set:
+            for layer in group[1:]:
+                layer.perm = group[0].perm
+        fused = [(sets[i][0], amd.QuantLinear.concat(group) if len(group) > 1 else group[0]) for i, group in enumerate(by_set)]
     for batch in (1, 8):
         m = batch * SEQ
         xin = {c: torch.randn(m, c, generator=gen, device=dev).half() for c in {c for c, _, _ in layers}}
@@ -277,7 +288,22 @@ def serving(torch, amd, sets, bits, dev):
         out["seq2048_batch%d" % batch] = {"tokens": m, "block_forward_ms": round(ms, 4), "w4a16_gemm_ms": round(ms_gemm, 4),
                                           "w4a16_tflops": round(tf, 1),
                                           "frac_of_f16_mfma_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+        # the Linears that read the same input as one layer each (QuantLinear.concat): q/k/v, gate/up
+        if fused is not None:
+            s3, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for c, layer in fused:
+                layer.forward_permuted(xp[c])
+            s3.record()
+            for _ in range(reps):
+                for c, layer in fused:
+                    layer.forward_permuted(xp[c])
+            e3.record()
+            torch.cuda.synchronize()
+            ms_f = s3.elapsed_time(e3) / reps
+            out["seq2048_batch%d" % batch].update({"fused_qkv_gateup_gemm_ms": round(ms_f, 4),
+                                                   "fused_qkv_gateup_tflops": round(flops / (ms_f * 1e-3) / 1e12, 1)})
         del xin, xp
+    out["expand_once_from_tokens"] = amd.QuantLinear.expand_min_tokens
     return out
 
 

@@ -219,7 +219,72 @@ __global__ __launch_bounds__(256) void permute_cols_wide_kernel(const unsigned s
     }
 }
 
+
+// Packed k-block operand -> dense 16-bit W[r][c] (columns in the operand's own order): what the packed GEMM
+// expands tile by tile, written out once.  Eight lanes share one (row, 64-column k-block): a lane turns 8
+// levels into 16 bytes, so the eight lanes of a row write one 128-byte line and a wave reads 8 rows x 32 (24)
+// contiguous bytes of packed words per k-block.  The arithmetic is deq16: the dense reconstruction's.
+template <int DTYPE, int BITS>
+__global__ __launch_bounds__(256) void wq_expand_kernel(const uint32_t *__restrict__ packed, const unsigned short *__restrict__ scale_t,
+                                                          const uint8_t *__restrict__ zero_t, int64_t r, int64_t c, int group_size,
+                                                          unsigned short *__restrict__ out)
+{
+    constexpr int KB_PER_BLOCK = 4;
+    const int lane8 = threadIdx.x & 7;
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (row >= r) return;
+    const int64_t n_kb = c / 64;
+#pragma unroll
+    for (int i = 0; i < KB_PER_BLOCK; ++i) {
+        const int64_t kb = (int64_t)blockIdx.y * KB_PER_BLOCK + i;
+        if (kb >= n_kb) break;
+        const int64_t col = kb * 64 + lane8 * 8;
+        const int64_t g = col / group_size;   // 8 consecutive columns lie in one group (group sizes are multiples of 32)
+        const unsigned short s_raw = scale_t[g * r + row];
+        const int z = zero_t[g * r + row];
+        unsigned short h[8];
+        if constexpr (BITS == 4) {
+            const uint32_t word = packed[(kb * r + row) * 8 + lane8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) h[v] = deq16<DTYPE>((int)((word >> (4 * w4_pairs_nibble(v))) & 15u), z, s_raw);
+        } else {
+            const uint32_t *w3 = packed + (kb * r + row) * 6 + (lane8 >> 2) * 3;
+            const uint32_t w[3] = {w3[0], w3[1], w3[2]};
+#pragma unroll
+            for (int v = 0; v < 8; ++v) h[v] = deq16<DTYPE>((int)w3_level(w, (lane8 & 3) * 8 + v), z, s_raw);
+        }
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = (unsigned)h[2 * w] | ((unsigned)h[2 * w + 1] << 16);
+        *reinterpret_cast<u32x4 *>(out + row * c + col) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int gq_wq_expand(void *w_out, const uint32_t *qweight_packed, const void *scale_t, const uint8_t *qzero_t,
+                            int64_t r, int64_t c, int group_size, int bits, int dtype, gq_stream_t stream)
+{
+    GQ_REQUIRE(w_out && qweight_packed && scale_t && qzero_t, "gq_wq_expand: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_wq_expand: bad dtype %d", dtype);
+    GQ_REQUIRE(bits == 3 || bits == 4, "gq_wq_expand: bits must be 3 or 4, got %d", bits);
+    GQ_REQUIRE(r > 0 && c > 0 && c % 64 == 0, "gq_wq_expand: bad shape r=%lld c=%lld (c must be a multiple of 64)", (long long)r,
+               (long long)c);
+    GQ_REQUIRE(group_size > 0 && group_size % 32 == 0 && c % group_size == 0,
+               "gq_wq_expand: group size %d must be a multiple of 32 dividing c=%lld", group_size, (long long)c);
+    GQ_REQUIRE(((uintptr_t)w_out & 15) == 0, "gq_wq_expand: w_out must be 16-byte aligned");
+    const dim3 grid((unsigned)gq_cdiv(r, 32), (unsigned)gq_cdiv(c / 64, 4));
+    GQ_REQUIRE(grid.y <= 65535, "gq_wq_expand: c=%lld is too wide", (long long)c);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short *sc = (const unsigned short *)scale_t;
+    unsigned short *out = (unsigned short *)w_out;
+    if (dtype == GQ_F16 && bits == 4) hipLaunchKernelGGL((wq_expand_kernel<GQ_F16, 4>), grid, dim3(256), 0, s, qweight_packed, sc, qzero_t, r, c, group_size, out);
+    else if (dtype == GQ_F16) hipLaunchKernelGGL((wq_expand_kernel<GQ_F16, 3>), grid, dim3(256), 0, s, qweight_packed, sc, qzero_t, r, c, group_size, out);
+    else if (bits == 4) hipLaunchKernelGGL((wq_expand_kernel<GQ_BF16, 4>), grid, dim3(256), 0, s, qweight_packed, sc, qzero_t, r, c, group_size, out);
+    else hipLaunchKernelGGL((wq_expand_kernel<GQ_BF16, 3>), grid, dim3(256), 0, s, qweight_packed, sc, qzero_t, r, c, group_size, out);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
 
 extern "C" int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int bits, int layout, uint32_t *packed,
                             gq_stream_t stream)

@@ -39,3 +39,7 @@ struct GqSgemmArgs {
 // starting from the old C (accumulate) or 0, which makes the result independent of tiling.
 // Requirements: m, n, k, lda, ldb, ldc multiples of 4; pointers 16-byte aligned.
 int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream);
+
+// Experiments and tests: 1 = every launch takes the compiler-scheduled kernels (also GQ_SGEMM=plain in the
+// environment); results are bit-identical either way.
+void gq_sgemm_set_plain(int on);

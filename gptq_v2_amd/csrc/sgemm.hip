@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "sgemm.h"
 
@@ -304,6 +305,335 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GqSgemmArgs g, int tiles_m, 
 #endif
 }
 
+
+// ---- 128x128 tiles that lie whole inside both operands, K range a whole number of 32-deep steps ----
+// The same product (every element one k-ascending fma chain on v_mfma_f32_32x32x2_f32, lanes 0-31
+// carrying k = 2s and lanes 32-63 k = 2s + 1 of sub-step s), with the schedule written by hand:
+//   * both operands go global -> LDS by LDS-DMA (16 bytes per lane, 1 KiB per wave instruction, no
+//     register staging): the eight pieces a wave owns of step t+1 are issued inside the first quarter
+//     of step t and waited for (vmcnt(0)) in front of the step's one barrier;
+//   * fragment reads are inline-asm ds_read_b32 with immediate offsets, those of the next pair of
+//     sub-steps issued between the MFMAs of the current pair, so no MFMA ever waits for the LDS;
+//   * the barrier of a step stands in front of its last eight MFMAs, and the first fragments of the
+//     next step are read behind it, under those MFMAs.
+// LDS images (16 KiB per operand and stage, two stages):
+//   k-contiguous source  : [128 rows][8 chunks of 16 B]; row r keeps source chunk c at slot c ^ ((r >> 1) & 7)
+//                          (the DMA writes LDS linearly, so the swizzle is applied to the source address)
+//   row-contiguous source: [32 k][32 chunks of 16 B];     odd k keep row chunk q at slot q ^ 8
+// so the 64 lanes of a fragment read (32 rows x 2 values of k) fall on at least 32 different banks.
+// Measured (4096^3 and the 4096 x 10496 x 512 accumulating update of the column loop, TFLOP/s; the fp32 MFMA
+// ceiling of the chip is 154.5, tools/src/mfma_rate_f32.hip): 104-124 -> 138-140 and 96-104 -> 119-122 against
+// the compiler-scheduled kernel above (which read every fragment right in front of its MFMA and waited for
+// all global loads at the top of every step); a k-contiguous operand whose leading dimension is a power of
+// two stays at 127 (its 128 rows map to few memory channels).  A k-step takes 9260 cycles for the two
+// workgroups of a CU against 8192 of pure MFMA issue.  A variant with 16-deep steps in three stages (48 KiB,
+// three workgroups per CU, pieces fetched two steps ahead) reached 6190 cycles per three workgroups and
+// step (99 % of the matrix pipe) and changed neither figure nor the bench: what is left is per launch, not
+// per step -- all first workgroups load their 64 KiB of C at once (a 9 us prologue), the last round is
+// partly empty, and a short-K update is 16 steps per tile.
+template <int B, int E, typename F>
+__device__ __forceinline__ void sg_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sg_for<B + 1, E>(f);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void sg_read_b32(float &dst, unsigned addr)
+{
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+constexpr int SG_OP_BYTES = 128 * 32 * 4;          // one operand image
+constexpr int SG_STAGE_BYTES = 2 * SG_OP_BYTES;    // A + B
+constexpr int SG_LDS_BYTES = 2 * SG_STAGE_BYTES;   // two stages: 64 KiB, two workgroups per CU
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GqSgemmArgs g, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool A_KM = (LAYOUT & GQ_A_KM) != 0;
+    constexpr bool B_KN = (LAYOUT & GQ_B_KN) != 0;
+    constexpr int BT = 128;
+#ifdef GQ_SG_TRACE
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_loop = 0;
+#endif
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    g.a += (int64_t)blockIdx.y * g.stride_a;
+    g.b += (int64_t)blockIdx.y * g.stride_b;
+    g.c += (int64_t)blockIdx.y * g.stride_c;
+    int tm, tn;
+    if (g.lower_only) {
+        const int bid = blockIdx.x;
+        int r = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= bid) ++r;
+        while (r * (r + 1) / 2 > bid) --r;
+        tm = r;
+        tn = bid - r * (r + 1) / 2;
+    } else if (g.trim == GQ_TRIM_K_LE_N) {
+        tn = tiles_n - 1 - (int)(blockIdx.x / tiles_m);
+        tm = blockIdx.x % tiles_m;
+    } else if (g.trim == GQ_TRIM_K_GE_N) {
+        tn = blockIdx.x / tiles_m;
+        tm = blockIdx.x % tiles_m;
+    } else if (g.trim == GQ_TRIM_K_LE_M) {
+        tm = tiles_m - 1 - (int)(blockIdx.x / tiles_n);
+        tn = blockIdx.x % tiles_n;
+    } else {
+        tm = blockIdx.x / tiles_n;
+        tn = blockIdx.x % tiles_n;
+    }
+    const int m0 = tm * BT, n0 = tn * BT;
+    int k_lo = 0, k_hi = g.k;
+    if (g.trim == GQ_TRIM_K_LE_N) k_hi = min(g.k, (tn + 1) * BT);
+    else if (g.trim == GQ_TRIM_K_GE_N) k_lo = min(g.k, tn * BT);
+    else if (g.trim == GQ_TRIM_K_LE_M) k_hi = min(g.k, (tm + 1) * BT);
+    const int n_steps = (k_hi - k_lo) / BKS;
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[2][2];
+    if (g.accumulate) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int col = n0 + (wc * 2 + b) * 32 + li;
+                    acc[a][b][e] = g.c[(int64_t)row * g.ldc + col];
+                }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+    }
+    const float sgn = g.negate ? -1.0f : 1.0f;
+
+    // ---- DMA sources: a uniform base that advances by one k-step, and a 32-bit lane offset per piece
+    unsigned voff_a[4], voff_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave * 4 + j;
+        if constexpr (A_KM) {
+            const int k = 2 * p + (lane >> 5), q = (lane & 31) ^ (8 * (lane >> 5));
+            voff_a[j] = (unsigned)(((int64_t)k * g.lda + 4 * q) * 4);
+        } else {
+            const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            voff_a[j] = (unsigned)(((int64_t)row * g.lda + 4 * c) * 4);
+        }
+        if constexpr (B_KN) {
+            const int k = 2 * p + (lane >> 5), q = (lane & 31) ^ (8 * (lane >> 5));
+            voff_b[j] = (unsigned)(((int64_t)k * g.ldb + 4 * q) * 4);
+        } else {
+            const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            voff_b[j] = (unsigned)(((int64_t)row * g.ldb + 4 * c) * 4);
+        }
+    }
+    const char *ua = reinterpret_cast<const char *>(A_KM ? g.a + (int64_t)k_lo * g.lda + m0 : g.a + (int64_t)m0 * g.lda + k_lo);
+    const char *ub = reinterpret_cast<const char *>(B_KN ? g.b + (int64_t)k_lo * g.ldb + n0 : g.b + (int64_t)n0 * g.ldb + k_lo);
+    const int64_t inc_a = (A_KM ? (int64_t)BKS * g.lda : (int64_t)BKS) * 4, inc_b = (B_KN ? (int64_t)BKS * g.ldb : (int64_t)BKS) * 4;
+    auto dma_a = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(ua + voff_a[j]),
+                                         GQ_LDS_PTR(void, smem_raw + stage * SG_STAGE_BYTES + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+    auto dma_b = [&](int stage, int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(ub + voff_b[j]),
+                                         GQ_LDS_PTR(void, smem_raw + stage * SG_STAGE_BYTES + SG_OP_BYTES + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses
+    const unsigned lds_base = (unsigned)(uintptr_t)GQ_LDS_PTR(char, smem_raw);
+    // k-contiguous image: address of chunk c of the lane's row (block u adds 4096, the second sub-step 8)
+    // row-contiguous image: address of the lane's row at k = lh for block u (sub-step s adds 1024)
+    unsigned addr_a[A_KM ? 2 : 8], addr_b[B_KN ? 2 : 8];
+    if constexpr (A_KM) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = wr * 64 + u * 32 + li;
+            addr_a[u] = lds_base + lh * 512 + ((((unsigned)r >> 2) ^ (8u * lh)) << 4) + ((r & 3) << 2);
+        }
+    } else {
+        const int r = wr * 64 + li;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) addr_a[c] = lds_base + r * 128 + lh * 4 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    if constexpr (B_KN) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = wc * 64 + u * 32 + li;
+            addr_b[u] = lds_base + SG_OP_BYTES + lh * 512 + ((((unsigned)r >> 2) ^ (8u * lh)) << 4) + ((r & 3) << 2);
+        }
+    } else {
+        const int r = wc * 64 + li;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) addr_b[c] = lds_base + SG_OP_BYTES + r * 128 + lh * 4 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+
+    float fa[2][2][2], fb[2][2][2];   // [set][sub-step of the pair][block]
+    // the eight fragment reads of sub-step pair C of stage ST into register set SET, read number I (0..7)
+    auto frag_read = [&](auto st_c, auto c_c, auto set_c, auto i_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_c)::value, C = decltype(c_c)::value, SET = decltype(set_c)::value, I = decltype(i_c)::value;
+        constexpr int OP = I >> 2, SUB = (I >> 1) & 1, U = I & 1;
+        if constexpr (OP == 0) {
+            if constexpr (A_KM) sg_read_b32<ST * SG_STAGE_BYTES + (2 * C + SUB) * 1024>(fa[SET][SUB][U], addr_a[U]);
+            else sg_read_b32<ST * SG_STAGE_BYTES + U * 4096 + SUB * 8>(fa[SET][SUB][U], addr_a[C]);
+        } else {
+            if constexpr (B_KN) sg_read_b32<ST * SG_STAGE_BYTES + (2 * C + SUB) * 1024>(fb[SET][SUB][U], addr_b[U]);
+            else sg_read_b32<ST * SG_STAGE_BYTES + U * 4096 + SUB * 8>(fb[SET][SUB][U], addr_b[C]);
+        }
+    };
+    auto reads_done = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    if (n_steps > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dma_a(0, j);
+            dma_b(0, j);
+        }
+        ua += inc_a;
+        ub += inc_b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        sg_for<0, 8>([&](auto i) { frag_read(I0{}, I0{}, I0{}, i); });
+        reads_done();
+    }
+#ifdef GQ_SG_TRACE
+    t_loop = __builtin_readcyclecounter();
+#endif
+
+    // one k-step on stage ST; MORE: another step follows (its pieces are fetched here, and its first
+    // fragments read behind the barrier)
+    auto k_step = [&](auto st_c, auto more_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
+        sg_for<0, 8>([&](auto c_c) {
+            constexpr int C = decltype(c_c)::value;
+            constexpr int SET = C & 1;
+            using NSET = std::integral_constant<int, SET ^ 1>;
+            // the sign goes on the A fragments (exact); those of the second sub-step behind the first MFMA
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fa[SET][0][u] *= sgn;
+            if constexpr (C == 7 && MORE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next step
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sg_for<0, 8>([&](auto i_c) {
+                constexpr int I = decltype(i_c)::value;
+                constexpr int SUB = I >> 2, A = (I >> 1) & 1, B = I & 1;
+                acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][SUB][A], fb[SET][SUB][B], acc[A][B], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (I == 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) fa[SET][1][u] *= sgn;
+                }
+                // the eight reads of the next pair behind the first four MFMAs: they have the other four to arrive
+                if constexpr (I < 4) {
+                    using R0 = std::integral_constant<int, 2 * I>;
+                    using R1 = std::integral_constant<int, 2 * I + 1>;
+                    if constexpr (C < 7) {
+                        frag_read(st_c, std::integral_constant<int, (C + 1) & 7>{}, NSET{}, R0{});
+                        frag_read(st_c, std::integral_constant<int, (C + 1) & 7>{}, NSET{}, R1{});
+                    } else if constexpr (MORE) {
+                        frag_read(std::integral_constant<int, ST ^ 1>{}, I0{}, NSET{}, R0{});
+                        frag_read(std::integral_constant<int, ST ^ 1>{}, I0{}, NSET{}, R1{});
+                    }
+                }
+                if constexpr (MORE && C < 2) {
+                    // pieces of the next step: A 0..3 in the first pair, B 0..3 in the second, one per two MFMAs
+                    if constexpr ((I & 1) == 1) {
+                        if constexpr (C == 0) dma_a(ST ^ 1, I >> 1);
+                        else dma_b(ST ^ 1, I >> 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (C < 7 || MORE) reads_done();
+        });
+        if constexpr (MORE) {
+            ua += inc_a;
+            ub += inc_b;
+        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        int step = 0;
+        for (; step + 2 < n_steps; step += 2) {
+            k_step(I0{}, T{});
+            k_step(I1{}, T{});
+        }
+        if (n_steps - step == 2) {
+            k_step(I0{}, T{});
+            k_step(I1{}, F{});
+        } else if (n_steps - step == 1) {
+            k_step(I0{}, F{});
+        }
+    }
+#ifdef GQ_SG_TRACE
+    const unsigned long long t_end = __builtin_readcyclecounter();
+#endif
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wr * 2 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int col = n0 + (wc * 2 + b) * 32 + li;
+                g.c[(int64_t)row * g.ldc + col] = acc[a][b][e];
+            }
+#ifdef GQ_SG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g_sg_trace && blockIdx.x == 300 && lane == 0) {
+        unsigned long long *o = g_sg_trace + wave * 8;
+        o[0] = t_begin; o[1] = t_loop; o[2] = t_end; o[3] = __builtin_readcyclecounter(); o[4] = r_begin;
+        o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = n_steps;
+    }
+#endif
+}
+
+int launch_sgemm_dma(const GqSgemmArgs &args, hipStream_t stream)
+{
+    const int tiles_m = args.m / 128, tiles_n = args.n / 128;
+    GQ_REQUIRE(!args.lower_only || tiles_m == tiles_n, "sgemm: lower_only needs a square tile grid");
+    const int n_blocks = args.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    void (*kern)(GqSgemmArgs, int, int) = nullptr;
+    switch (args.layout) {
+    case GQ_A_MK | GQ_B_NK: kern = sgemm_dma_kernel<GQ_A_MK | GQ_B_NK>; break;
+    case GQ_A_MK | GQ_B_KN: kern = sgemm_dma_kernel<GQ_A_MK | GQ_B_KN>; break;
+    case GQ_A_KM | GQ_B_NK: kern = sgemm_dma_kernel<GQ_A_KM | GQ_B_NK>; break;
+    case GQ_A_KM | GQ_B_KN: kern = sgemm_dma_kernel<GQ_A_KM | GQ_B_KN>; break;
+    default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
+    }
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(n_blocks, std::max(args.batch, 1)), dim3(256), SG_LDS_BYTES, stream, args, tiles_m, tiles_n);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 template <int BT>
 int launch_sgemm(const GqSgemmArgs &args, hipStream_t stream)
 {
@@ -335,6 +665,9 @@ extern "C" int gq_debug_sg_trace(unsigned long long *buf)
 }
 #endif
 
+static bool g_sgemm_plain = false;
+void gq_sgemm_set_plain(int on) { g_sgemm_plain = on != 0; }
+
 int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
 {
     GQ_REQUIRE(args.a && args.b && args.c, "sgemm: NULL operand");
@@ -352,6 +685,14 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
                "sgemm: batch strides must be multiples of 4");
     const int64_t blocks128 = (args.lower_only ? tm * (tm + 1) / 2 : tm * tn) * std::max(args.batch, 1);
     if (blocks128 < 256) return launch_sgemm<64>(args, stream);
+    // whole 128-tiles, whole k-steps, lane offsets of the DMA within 32 bits: the hand-scheduled kernel
+    static const bool plain_env = [] { const char *e = getenv("GQ_SGEMM"); return e && e[0] == 'p'; }();
+    const bool plain = plain_env || g_sgemm_plain;
+    const int64_t span_a = (args.layout & GQ_A_KM) ? 32 * args.lda + 128 : 128 * args.lda + 32;
+    const int64_t span_b = (args.layout & GQ_B_KN) ? 32 * args.ldb + 128 : 128 * args.ldb + 32;
+    if (!plain && args.m % 128 == 0 && args.n % 128 == 0 && args.k % BKS == 0 && span_a < ((int64_t)1 << 29) &&
+        span_b < ((int64_t)1 << 29))
+        return launch_sgemm_dma(args, stream);
     return launch_sgemm<128>(args, stream);
 }
 

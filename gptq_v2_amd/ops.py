@@ -404,6 +404,36 @@ def w4a16_gemm(x: torch.Tensor, qweight_packed: torch.Tensor, scale_t: torch.Ten
     _lib.check(rc, "gq_wq_gemm")
     return y
 
+def _check_packed(qweight_packed, scale_t, qzero_t, group_size, bits, what):
+    _check(qweight_packed, "qweight_packed", torch.int32, 3)
+    _check(scale_t, "scale_t", None, 2)
+    _check(qzero_t, "qzero_t", torch.uint8, 2)
+    if bits not in (3, 4):
+        raise ValueError(f"{what}: bits must be 3 or 4")
+    c, r = qweight_packed.shape[0] * 64, qweight_packed.shape[1]
+    if (qweight_packed.shape[2] != (8 if bits == 4 else 6) or group_size <= 0 or c % group_size
+            or scale_t.shape != (c // group_size, r) or qzero_t.shape != scale_t.shape):
+        raise ValueError(f"{what}: inconsistent shapes")
+    return r, c
+
+
+def wq_expand(qweight_packed: torch.Tensor, scale_t: torch.Tensor, qzero_t: torch.Tensor, group_size: int,
+              bits: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Dense (R, C) weight of scale_t's type from a packed operand, columns in the operand's own order:
+    the values ``w4a16_gemm`` multiplies by, written out once."""
+    r, c = _check_packed(qweight_packed, scale_t, qzero_t, group_size, bits, "wq_expand")
+    code = _dtype_code(scale_t)
+    if out is None:
+        out = torch.empty(r, c, dtype=scale_t.dtype, device=scale_t.device)
+    elif out.shape != (r, c) or out.dtype != scale_t.dtype or not out.is_contiguous() or out.device != scale_t.device:
+        raise ValueError("wq_expand: out must be a contiguous (R, C) tensor of the scales' type on their device")
+    with torch.cuda.device(scale_t.device):
+        rc = _lib.load().gq_wq_expand(_p(out), _p(qweight_packed), _p(scale_t), _p(qzero_t), r, c, int(group_size), int(bits),
+                                      code, _stream(scale_t))
+    _lib.check(rc, "gq_wq_expand")
+    return out
+
+
 def gemm_nt(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """x (M, K) @ weight (N, K)^T -> (M, N), fp16 or bf16, fp32 accumulation: the dense Linear forward
     of the calibration replay (llama.py:176-177) on the hand-written MFMA kernel."""

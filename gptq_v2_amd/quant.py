@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -437,14 +439,57 @@ class QuantLinear(nn.Module):
             x2 = ops.permute_columns(x2, self.perm)
         return x2.reshape(shape)
 
+    # From this many tokens per call on, the levels are expanded once into a transient dense weight and the
+    # dense MFMA kernel multiplies by it (the packed kernel expands the same levels again for every 256-token
+    # band).  Same product bit for bit; weights stay packed at rest.  0 = never.  GQ_WQ_EXPAND_MIN_TOKENS
+    # in the environment sets the initial value.
+    expand_min_tokens = int(os.environ.get("GQ_WQ_EXPAND_MIN_TOKENS", "2048"))
+
+    def _expands(self, tokens: int) -> bool:
+        least = self.expand_min_tokens
+        if least <= 0:
+            return False
+        # a layer of fewer than 8192 rows takes twice as many tokens to win back the pass over its weights
+        # (measured on Llama-2-7B shapes: from 2048 tokens at 11008 rows and more, from 4096 at 4096 rows)
+        return tokens >= (least if self.out_features >= 8192 else 2 * least)
+
     @torch.no_grad()
     def forward_permuted(self, x_permuted: torch.Tensor) -> torch.Tensor:
         shape = x_permuted.shape
         x2 = x_permuted.reshape(-1, shape[-1])
         if x2.dtype != self.dtype:
             raise NotImplementedError(f"this QuantLinear takes {self.dtype} activations, got {x2.dtype}")
-        y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size, bits=3 if self.dense3 else 4)
+        bits = 3 if self.dense3 else 4
+        if self._expands(x2.shape[0]):
+            dense = ops.wq_expand(self.qweight, self.scales, self.qzeros, self.group_size, bits=bits)
+            y = ops.gemm_nt(x2.contiguous(), dense)
+        else:
+            y = ops.w4a16_gemm(x2.contiguous(), self.qweight, self.scales, self.qzeros, self.group_size, bits=bits)
         return y.reshape(*shape[:-1], self.out_features)
+
+    @classmethod
+    @torch.no_grad()
+    def concat(cls, layers) -> "QuantLinear":
+        """One layer whose rows are the rows of ``layers`` in order (q/k/v, gate/up: Linears that read the
+        same input, quantised against the same Hessian): one activation gather and one GEMM launch with
+        three times the tiles instead of three.  The layers must agree in input width, act-order, fine
+        group size, storage and type; ``forward`` returns the outputs side by side, each bit for bit what
+        the layer alone returns (split with ``Tensor.split([l.out_features for l in layers], -1)``)."""
+        layers = list(layers)
+        first = layers[0]
+        for other in layers[1:]:
+            if (other.in_features != first.in_features or other.group_size != first.group_size or other.dense3 != first.dense3
+                    or other.dtype != first.dtype or (other.perm is None) != (first.perm is None)
+                    or (first.perm is not None and not torch.equal(other.perm, first.perm))):
+                raise ValueError("QuantLinear.concat: layers differ in input width, act-order, group size, storage or type")
+        out = cls(first.in_features, sum(l.out_features for l in layers), first.group_size, max(l.bits for l in layers),
+                  first.dtype, dense3=first.dense3)
+        # fine-grid description only: a concatenation is a serving object, unpack() of its parts gives the metadata back
+        out.qweight = torch.cat([l.qweight for l in layers], dim=1).contiguous()
+        out.scales = torch.cat([l.scales for l in layers], dim=1).contiguous()
+        out.qzeros = torch.cat([l.qzeros for l in layers], dim=1).contiguous()
+        out.perm = first.perm
+        return out
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -293,6 +293,15 @@ int gq_wq_gemm(void *y, const void *x, const uint32_t *qweight_packed, const voi
                const uint8_t *qzero_t, int64_t m, int64_t r, int64_t c, int group_size, int bits, int dtype,
                gq_stream_t stream);
 
+/* The dense 16-bit weight a packed operand stands for, w_out[r][c] row-major with the columns in the operand's
+ * own (act-order) sequence: W[r][k] = (q - z) * scale rounded once to `dtype`, the value gq_wq_gemm multiplies
+ * by and gq_dequantize writes (ref: quant.py:222-237, 262-279, up to the column order).  With many tokens per
+ * call (prefill) every 256-token band of a packed GEMM expands the same levels again; expanding once into a
+ * transient buffer and running gq_gemm_nt on it gives the same product bit for bit and is faster from a few
+ * thousand tokens on.  Weights stay packed at rest.  w_out 16-byte aligned, r * c * 2 bytes. */
+int gq_wq_expand(void *w_out, const uint32_t *qweight_packed, const void *scale_t, const uint8_t *qzero_t,
+                 int64_t r, int64_t c, int group_size, int bits, int dtype, gq_stream_t stream);
+
 /* Which kernel gq_wq_gemm runs for 4-bit operands: 0 = chosen by shape (the default), 1 = the stream
  * kernel (one barrier per k-step, expansion between the matrix instructions), 2 = the split kernel
  * (expansion and matrix waves apart; the one gq_w4a16_gemm runs).  Returns the previous setting, -1 on a

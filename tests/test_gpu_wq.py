@@ -161,3 +161,61 @@ def test_stream_kernel_every_k_step_count(amd, gpu, bits, dtype):
             assert torch.equal(y, w.t()), steps
     finally:
         lib.gq_set_wq_kernel(before)
+
+
+def _random_meta(gen, gpu, r, c, group, bits, dtype):
+    return {"qweight": torch.randint(0, 1 << bits, (r, c), generator=gen, dtype=torch.uint8).to(gpu),
+            "scale": (torch.rand(r, c // group, generator=gen) * 0.01 + 0.002).to(dtype).to(gpu),
+            "qzero": torch.randint(0, 1 << bits, (r, c // group), generator=gen, dtype=torch.uint8).to(gpu),
+            "qscale": None, "sscale": None, "perm_inv": torch.randperm(c, generator=gen).to(torch.int16),
+            "group_sizes": torch.full([c // group], group, dtype=torch.int16),
+            "group_bit_widths": torch.full([c // group], bits, dtype=torch.uint8)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bits,group", [(4, 128), (4, 32), (3, 64)])
+def test_expand_once_equals_reconstruction_and_packed_forward(amd, gpu, dtype, bits, group):
+    """gq_wq_expand writes the dense weight of a packed operand: equal to reconstruct_nn_linear's weight with
+    the columns in act-order, bit for bit; the forward that expands once and runs the dense kernel returns the
+    packed kernel's product bit for bit (ragged token and row counts included)."""
+    gen = torch.Generator().manual_seed(1000 * bits + group)
+    r, c = 8192 + 40, 384
+    meta = _random_meta(gen, gpu, r, c, group, bits, dtype)
+    layer = amd.QuantLinear.from_quant_meta(meta, gpu, dense3=bits == 3)
+    dense = amd.ops.wq_expand(layer.qweight, layer.scales, layer.qzeros, layer.group_size, bits=3 if layer.dense3 else 4)
+    w = amd.reconstruct_nn_linear(meta, dtype=dtype, device=gpu).weight.data
+    assert torch.equal(dense, w[:, layer.perm.long()])
+    x = torch.randn(300, c, generator=gen).to(dtype).to(gpu)
+    layer.expand_min_tokens = 0
+    packed = layer(x)
+    layer.expand_min_tokens = 256
+    assert layer._expands(x.shape[0])
+    assert torch.equal(layer(x), packed)
+    with pytest.raises(ValueError):
+        amd.ops.wq_expand(layer.qweight, layer.scales, layer.qzeros, layer.group_size, bits=3 if layer.dense3 else 4,
+                          out=torch.empty(r, c + 64, dtype=dtype, device=gpu))
+
+
+def test_quantlinear_concat_returns_the_parts_side_by_side(amd, gpu):
+    """q/k/v as one layer: one gather, one launch, outputs equal to the three layers' own bit for bit, with the
+    packed kernel and with the expand-once path."""
+    gen = torch.Generator().manual_seed(99)
+    c, rows = 512, [256, 128, 320]
+    perm_inv = torch.randperm(c, generator=gen).to(torch.int16)
+    parts = []
+    for r in rows:
+        meta = _random_meta(gen, gpu, r, c, 128, 4, torch.float16)
+        meta["perm_inv"] = perm_inv
+        parts.append(amd.QuantLinear.from_quant_meta(meta, gpu))
+    fused = amd.QuantLinear.concat(parts)
+    assert fused.out_features == sum(rows) and fused.qweight.shape == (c // 64, sum(rows), 8)
+    x = torch.randn(3, 100, c, generator=gen).half().to(gpu)
+    for least in (0, 64):
+        fused.expand_min_tokens = least
+        ys = fused(x).split(rows, dim=-1)
+        for part, y in zip(parts, ys):
+            part.expand_min_tokens = 0
+            assert torch.equal(part(x), y)
+    other = amd.QuantLinear.from_quant_meta(_random_meta(gen, gpu, 64, c, 128, 4, torch.float16), gpu)   # its own act-order
+    with pytest.raises(ValueError):
+        amd.QuantLinear.concat([parts[0], other])

@@ -41,15 +41,17 @@ def run():
     if hasattr(lib, "gq_debug_sg_trace"):
         trace = torch.zeros(32, device=dev, dtype=torch.int64)
         lib.gq_debug_sg_trace(p(trace))
-        m = n = k = 4096
-        a = torch.randn(m, k, device=dev); b = torch.randn(n, k, device=dev); c = torch.zeros(m, n, device=dev)
-        for _ in range(2): lib.gq_debug_sgemm(p(a), p(b), p(c), m, n, k, 0, 0, 0, 0, 0, None)
-        torch.cuda.synchronize()
-        t = trace.cpu().view(4, 8)
-        for w in range(4):
-            T = [int(v) for v in t[w]]
-            print(f"wave {w}: prologue {T[1]-T[0]} loop {T[2]-T[1]} ({(T[2]-T[1])/max(T[6],1):.0f}/step of 32 k; pure MFMA issue 4096) epilogue {T[3]-T[2]} "
-                  f"clock {(T[3]-T[0])/max((T[5]-T[4])*10,1):.2f} GHz")
+        for (m, n, k, layout, acc) in [(4096, 4096, 4096, 2, 0), (4096, 10496, 512, 3, 1)]:
+            a = torch.randn((k, m) if layout & 1 else (m, k), device=dev); b = torch.randn((k, n) if layout & 2 else (n, k), device=dev)
+            c = torch.zeros(m, n, device=dev)
+            for _ in range(2): lib.gq_debug_sgemm(p(a), p(b), p(c), m, n, k, layout, 0, 0, acc, 0, None)
+            torch.cuda.synchronize()
+            t = trace.cpu().view(4, 8)
+            print((m, n, k), "layout", layout, "accumulate", acc)
+            for w in range(4):
+                T = [int(v) for v in t[w]]
+                print(f"wave {w}: prologue {T[1]-T[0]} loop {T[2]-T[1]} ({(T[2]-T[1])/max(T[6],1):.0f}/step of 32 k; pure MFMA issue 4096) epilogue {T[3]-T[2]} "
+                      f"clock {(T[3]-T[0])/max((T[5]-T[4])*10,1):.2f} GHz")
 
 if __name__ == "__main__":
     build() if sys.argv[1:2] == ["build"] else run()
