@@ -124,6 +124,10 @@ class HessianHook:
 # and fill each other's gaps (measured on the Llama-2-7B block: 32.6 -> 27.4 ms).  Slicing the
 # rows of ONE Linear over streams does not pay: a slice's chain is barely shorter than the whole
 # layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1.
+# The opposite -- the rows of the set's Linears stacked into ONE column loop (bit for bit the same levels;
+# block launches of three times the workgroups, trailing updates of three times the tiles) -- was measured
+# too and is slower: 21.2 against 19.9 ms per Llama-2-7B block.  A stacked gate/up launch is 344 workgroups
+# of one per CU, two rounds, and one chain cannot run a block kernel beside another layer's update GEMM.
 # HIP gives a process 4 hardware queues by default and streams beyond that share a queue, where a
 # wait of one stream holds up the kernels of the other behind it: three side streams plus the
 # caller's stream stay within the four (no set of a Llama block has more than three Linears).
