@@ -151,11 +151,22 @@ __global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64
 // above the diagonal).  A pivot that is not a positive finite number raises *status.
 //
 // Cholesky: 8 panels of 16 columns.  Per panel (a) one wave factors the 16x16 diagonal block and
-// inverts it with the rows on lanes and every broadcast a v_readlane (no LDS, no barrier),
-// (b) 112 row-threads form their 16 entries of the panel as  A21 * L11^-T  from the broadcast
-// inverse, (c) all 256 threads apply the rank-16 update to the trailing lower triangle in 4x4
-// register tiles.  Inverse: the 16x16 diagonal inverses are doubled three times,
-// inv([A 0; B D]) = [A^-1 0; -D^-1 (B A^-1) D^-1], again in 4x4 register tiles.
+// inverts it with the rows on lanes and every broadcast a DPP row broadcast (no LDS, no barrier),
+// (b) the panel below it,  A21 * L11^-T, and (c) the rank-16 update of the trailing lower triangle
+// run on 16x16 blocks of v_mfma_f32_16x16x4_f32, one block per wave and turn.  (a) is a chain of
+// dependent instructions on one wave and the longest phase, so only the part of (c) that the next
+// panel reads -- its own 16 columns, (c1) -- stands between (b) and the next (a); the rest, (c2),
+// runs on waves 1-3 beside that (a).  Inverse: the 16x16 diagonal inverses are doubled three times,
+// inv([A 0; B D]) = [A^-1 0; -D^-1 (B A^-1) D^-1], on the same MFMA blocks with every fragment of
+// a block read before its first MFMA.
+// Cycles of one leaf (tools/trace_leaf.py): 84k with scalar-FMA panels and updates and everything in
+// sequence, 61-62k now -- factorisations of the diagonal blocks 16-17k (about 130 cycles per pivot),
+// their inverses 13k, panels and (c1) 5-6k each, the two passes of the doubling 5k each (15k before
+// the zeros of the triangular operands were skipped), load and store 6k.  Measured and dropped: the
+// inverse of a diagonal block on wave 1 beside the NEXT factorisation, with the panels as triangular
+// solves (one thread per row) so that nothing waits for it -- 71k: a solve is 120 broadcast LDS reads
+// and a 32-deep chain per row (1.9k cycles per panel against 0.7k for the MFMA form), and the inverse
+// read back from LDS on another wave took longer than the factorisation beside it.
 constexpr int LLD = 132;                 // LDS row stride (floats): 16-byte aligned rows, 16 rows cover all banks
 constexpr int PB = 16;                   // panel width
 constexpr int SLD = 68;                  // stride of the 64x64 product scratch
@@ -172,6 +183,28 @@ template <int K>
 __device__ __forceinline__ float row_bcast(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+
+// acc += (lane K of v, within every 16-lane row) * m as ONE instruction: the row broadcast is the DPP operand
+// of a v_fmac (through the builtin hipcc emits a zeroing move, a DPP move and a VOP3 fma: three instructions
+// per update of the chain below).  A DPP operand may not have been written by the two instructions in front of
+// it and hipcc does not look into inline asm, so FRESH = true (v has just been produced) waits by itself.
+template <int K, bool FRESH = false>
+__device__ __forceinline__ void fmac_bcast(float &acc, float v, float m)
+{
+    if constexpr (FRESH)
+        asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(m), "n"(K));
+    else
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(m), "n"(K));
+}
+
+// lane K of every 16-lane row of a value the asm above may just have written
+template <int K>
+__device__ __forceinline__ float row_bcast_fresh(float v)
+{
+    float out;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "n"(K));
+    return out;
 }
 
 template <int B, int E, typename F>
@@ -202,6 +235,47 @@ __device__ __forceinline__ void tri_index(int t, int &ti, int &tj)
     while (r * (r + 1) / 2 > t) --r;
     ti = r;
     tj = t - r * (r + 1) / 2;
+}
+
+// N 16x16 blocks of the trailing update on one wave: a[r0.., q0..] -= L[r0.., k0..k0+16) * L[q0.., k0..k0+16)^T,
+// four v_mfma_f32_16x16x4_f32 per block with the old block as the accumulator input (lane l feeds
+// A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15] and owns D[4 (l >> 4) + e][l & 15]).  All reads
+// of the N blocks are issued first and their MFMAs interleaved: one block alone is an LDS round trip, a chain
+// of four dependent MFMAs and the writes, about 700 cycles of latency.  With the row stride of 132 floats all
+// four access patterns are conflict-free.
+template <int N>
+__device__ __forceinline__ void trail_n(float *a, int k0, const int *r0, const int *q0, int l15, int lq)
+{
+    f32x4 acc[N];
+    float av[N][4], bv[N][4];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float *d = a + (r0[n] + 4 * lq) * LLD + q0[n] + l15;
+        acc[n] = f32x4{d[0], d[LLD], d[2 * LLD], d[3 * LLD]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            av[n][q] = -a[(r0[n] + l15) * LLD + k0 + 4 * q + lq];
+            bv[n][q] = a[(q0[n] + l15) * LLD + k0 + 4 * q + lq];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n][q], bv[n][q], acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float *d = a + (r0[n] + 4 * lq) * LLD + q0[n] + l15;
+        d[0] = acc[n][0]; d[LLD] = acc[n][1]; d[2 * LLD] = acc[n][2]; d[3 * LLD] = acc[n][3];
+    }
+}
+
+// `count` (1..4, wave-uniform) blocks at once
+__device__ __forceinline__ void trail_blocks(float *a, int k0, const int *r0, const int *q0, int count, int l15, int lq)
+{
+    if (count == 4) trail_n<4>(a, k0, r0, q0, l15, lq);
+    else if (count == 3) trail_n<3>(a, k0, r0, q0, l15, lq);
+    else if (count == 2) trail_n<2>(a, k0, r0, q0, l15, lq);
+    else if (count == 1) trail_n<1>(a, k0, r0, q0, l15, lq);
 }
 
 #ifdef GQ_LEAF_TRACE
@@ -243,8 +317,27 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
     LF_ADD(0);
     bool bad = false;
 
+    const int l15 = tid & 15, lq = (tid & 63) >> 4;
     for (int p = 0; p < NB / PB; ++p) {
         const int c0 = p * PB, c1 = c0 + PB;
+        // (c2) of the previous panel on waves 1-3: its update of every 16x16 block right of this panel's columns
+        // (block rows and columns counted from c1; the lower triangle of an (n x n) block grid)
+        if (tid >= 64 && p > 0) {
+            const int n = (NB - c1) / PB, total = n * (n + 1) / 2;
+            for (int t0 = wid - 1; t0 < total; t0 += 12) {   // the wave's blocks t0, t0 + 3, ..., four at a time
+                int r0[4], q0[4], count = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = min(t0 + 3 * u, total - 1);
+                    int ti, tj;
+                    tri_index(t, ti, tj);
+                    r0[u] = c1 + PB * ti;
+                    q0[u] = c1 + PB * tj;
+                    count += t0 + 3 * u < total;
+                }
+                trail_blocks(a, c0 - PB, r0, q0, count, l15, lq);
+            }
+        }
         // (a) diagonal block: lane i (< 16) of wave 0 holds row i
         if (tid < 64) {
             const int i = tid & 15;
@@ -261,7 +354,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
             float rinv[PB];
             static_for<0, PB>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const float dj = row_bcast<j>(d[j]);
+                const float dj = row_bcast_fresh<j>(d[j]);
                 if (!(dj > 0.0f) || !(dj < 3.0e38f)) bad = true;
                 const float rj = rsqrt_nr(dj);
                 const float lj = __fmul_rn(d[j], rj);   // lane j: dj / sqrt(dj) = sqrt(dj)
@@ -270,19 +363,25 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
                 const float nlj = -lj;
                 static_for<j + 1, PB>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    d[k] = fmaf(nlj, row_bcast<k>(lj), d[k]);
+                    fmac_bcast<k, k == j + 1>(d[k], lj, nlj);   // d[k] -= L[i][j] * L[k][j]
                 });
             });
+            LF_ADD(1);
             // inverse: lane c holds column c, xi[r] = (L11^-1)[r][c]
+            // (column by column: once xi[k] is known every later row takes its term, so the 15 - k updates are
+            // independent of each other and only xi[k] -> the update of row k + 1 -> xi[k + 1] is a chain; each
+            // row's sum still adds its terms in ascending k)
             float xi[PB];
-            static_for<0, PB>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                float sacc = i == r ? 1.0f : 0.0f;
-                static_for<0, r>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    sacc = fmaf(-row_bcast<r>(d[k]), xi[k], sacc);
+#pragma unroll
+            for (int r = 0; r < PB; ++r) xi[r] = i == r ? 1.0f : 0.0f;
+            static_for<0, PB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                xi[k] = __fmul_rn(xi[k], rinv[k]);
+                const float nxk = -xi[k];
+                static_for<k + 1, PB>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    fmac_bcast<r>(xi[r], d[k], nxk);   // xi[r] -= L[r][k] * xi[k]
                 });
-                xi[r] = __fmul_rn(sacc, rinv[r]);
             });
             if (tid < PB) {
 #pragma unroll
@@ -300,78 +399,45 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
                 }
             }
         }
+        LF_ADD(6);
         __syncthreads();
-        LF_ADD(1);
-        // (b) panel below the diagonal block: row t of  A21 * L11^-T, its 16 entries split over two
-        // threads (columns 0..11 and 12..15: 78 and 58 multiply-adds of the triangular product);
-        // the product replaces its own input, so everybody reads before anybody writes
-        {
-            const int row = tid & (NB - 1), hi = tid >> 7;
-            const bool act = row >= c1;
-            float ar[PB], out[12];
-            if (act) {
+        LF_ADD(7);
+        if (c1 == NB) break;
+        // (b) panel below the diagonal block, L21 = A21 * L11^-T, one 16-row block per wave and turn on four
+        // v_mfma_f32_16x16x4_f32 (B[k][j] = L11^-1[j][k]; its zeros above the diagonal are multiplied through).
+        // A block replaces its own input: the wave has read its four fragments before it writes.
+        const int nrb = (NB - c1) / PB;   // 16-row blocks below the diagonal block
+        if (wid < nrb) {   // the wave's blocks wid and wid + 4 (at most seven blocks), both at once
+            const bool two = wid + 4 < nrb;
+            const int ra = c1 + PB * wid, rb = c1 + PB * (two ? wid + 4 : wid);
+            float av[2][4], bv[4];
 #pragma unroll
-                for (int k4 = 0; k4 < PB; k4 += 4) {
-                    const f32x4 v = lds4(a + row * LLD + c0 + k4);
-                    ar[k4] = v[0]; ar[k4 + 1] = v[1]; ar[k4 + 2] = v[2]; ar[k4 + 3] = v[3];
-                }
-                if (hi == 0) {
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) {
-                        float sacc = 0.0f;
-#pragma unroll
-                        for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
-                        out[j] = sacc;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 12; j < PB; ++j) {
-                        float sacc = 0.0f;
-#pragma unroll
-                        for (int k = 0; k <= j; ++k) sacc = fmaf(ar[k], tinv[j * PB + k], sacc);
-                        out[j - 12] = sacc;
-                    }
-                }
+            for (int q = 0; q < 4; ++q) {
+                av[0][q] = a[(ra + l15) * LLD + c0 + 4 * q + lq];
+                av[1][q] = a[(rb + l15) * LLD + c0 + 4 * q + lq];
+                bv[q] = tinv[l15 * PB + 4 * q + lq];
             }
-            __syncthreads();
-            if (act) {
-                if (hi == 0) {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                    for (int k4 = 0; k4 < 12; k4 += 4)
-                        st4(a + row * LLD + c0 + k4, f32x4{out[k4], out[k4 + 1], out[k4 + 2], out[k4 + 3]});
-                } else {
-                    st4(a + row * LLD + c0 + 12, f32x4{out[0], out[1], out[2], out[3]});
-                }
+            for (int q = 0; q < 4; ++q) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][q], bv[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][q], bv[q], acc[1], 0, 0, 0);
+            }
+            float *dst = a + (ra + 4 * lq) * LLD + c0 + l15;
+            dst[0] = acc[0][0]; dst[LLD] = acc[0][1]; dst[2 * LLD] = acc[0][2]; dst[3 * LLD] = acc[0][3];
+            if (two) {
+                dst = a + (rb + 4 * lq) * LLD + c0 + l15;
+                dst[0] = acc[1][0]; dst[LLD] = acc[1][1]; dst[2 * LLD] = acc[1][2]; dst[3 * LLD] = acc[1][3];
             }
         }
         __syncthreads();
         LF_ADD(2);
-        // (c) trailing lower triangle -= L21 L21^T, 4x4 tiles
-        const int nt = (NB - c1) / 4;
-        for (int t = tid; t < nt * (nt + 1) / 2; t += 256) {
-            int ti, tj;
-            tri_index(t, ti, tj);
-            const int r0 = c1 + 4 * ti, q0 = c1 + 4 * tj;
-            f32x4 acc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = lds4(a + (r0 + u) * LLD + q0);
-#pragma unroll
-            for (int k4 = 0; k4 < PB; k4 += 4) {
-                f32x4 lr[4], lc[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    lr[u] = lds4(a + (r0 + u) * LLD + c0 + k4);
-                    lc[u] = lds4(a + (q0 + u) * LLD + c0 + k4);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) acc[u][v] = fmaf(-lr[u][k], lc[v][k], acc[u][v]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) st4(a + (r0 + u) * LLD + q0, acc[u]);
+        // (c1) the next panel's columns (its diagonal block and everything below) -= L21 L21^T: the only part of
+        // the trailing update the next diagonal block and panel wait for.  The rest, (c2), runs beside the next
+        // diagonal block at the top of the loop.
+        if (wid < nrb) {
+            const int r0[2] = {c1 + PB * wid, c1 + PB * (wid + 4)}, q0[2] = {c1, c1};
+            trail_blocks(a, c0, r0, q0, wid + 4 < nrb ? 2 : 1, l15, lq);
         }
         __syncthreads();
         LF_ADD(3);
@@ -383,48 +449,86 @@ __global__ __launch_bounds__(256) void leaf_kernel(const float *__restrict__ w, 
     // A[row l & 15][k = l >> 4] and B[k = l >> 4][column l & 15] and owns D[4 (l >> 4) + e][l & 15]);
     // operands are read as stored: the zeros above the diagonals of X11 and X22 are multiplied
     // through rather than skipped
-    {
-        const int l15 = tid & 15, lq = (tid & 63) >> 4;
-        for (int s = PB; s < NB; s *= 2) {
-            const int bpd = s / 16, bpp = bpd * bpd;   // 16x16 blocks per dimension / per pair
-            const int n_pairs = NB / (2 * s);
-            // pass 1: T = L21 * X11 into the scratch, pairs stacked by rows (n_pairs * s <= 64 rows)
-            for (int t = wid; t < n_pairs * bpp; t += 4) {
-                const int pair = t / bpp, tt = t % bpp, ti = tt / bpd, tj = tt % bpd;
-                const int b = pair * 2 * s;
-                const float *pl = a + (b + s + 16 * ti + l15) * LLD + b + lq;      // A[i][k] = L21[i][k]
-                const float *px = x + (b + lq) * LLD + b + 16 * tj + l15;          // B[k][j] = X11[k][j]
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < s; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pl[k], px[k * LLD], acc, 0, 0, 0);
-                float *dst = sc + (pair * s + 16 * ti + 4 * lq) * SLD + 16 * tj + l15;
-                dst[0] = acc[0]; dst[SLD] = acc[1]; dst[2 * SLD] = acc[2]; dst[3 * SLD] = acc[3];
+    static_for<0, 3>([&](auto level) {
+        constexpr int s = PB << decltype(level)::value;   // 16, 32, 64
+        constexpr int bpd = s / 16, nq = s / 4;           // 16x16 blocks per dimension of a half, MFMAs per full K range
+        // Every level has exactly four (pair, block row) and four (pair, block column) combinations: one per wave.
+        const int pair = wid / bpd, mine = wid % bpd;
+        const int b = pair * 2 * s;
+        // pass 1: T = L21 * X11 into the scratch, pairs stacked by rows (n_pairs * s <= 64 rows).  The wave owns
+        // block row `mine` of its pair: its L21 fragments serve all block columns tj, and X11 is lower
+        // triangular, so column tj only needs k >= 16 tj.  All fragments are read first; the MFMAs of the
+        // block columns are interleaved so that no MFMA waits for its predecessor.
+        {
+            float av[nq], bv[bpd][nq];
+            const float *pl = a + (b + s + 16 * mine + l15) * LLD + b + lq;      // A[i][k] = L21[i][k]
+#pragma unroll
+            for (int q = 0; q < nq; ++q) av[q] = pl[4 * q];
+            static_for<0, bpd>([&](auto tjc) {
+                constexpr int tj = decltype(tjc)::value;
+                const float *px = x + (b + lq) * LLD + b + 16 * tj + l15;        // B[k][j] = X11[k][j]
+#pragma unroll
+                for (int q = 4 * tj; q < nq; ++q) bv[tj][q] = px[4 * q * LLD];
+            });
+            f32x4 acc[bpd];
+#pragma unroll
+            for (int tj = 0; tj < bpd; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, nq>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<0, q / 4 + 1>([&](auto tjc) {
+                    constexpr int tj = decltype(tjc)::value;
+                    acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[tj][q], acc[tj], 0, 0, 0);
+                });
+            });
+#pragma unroll
+            for (int tj = 0; tj < bpd; ++tj) {
+                float *dst = sc + (pair * s + 16 * mine + 4 * lq) * SLD + 16 * tj + l15;
+                dst[0] = acc[tj][0]; dst[SLD] = acc[tj][1]; dst[2 * SLD] = acc[tj][2]; dst[3 * SLD] = acc[tj][3];
             }
-            __syncthreads();
-            LF_ADD(4);
-            // pass 2: X21 = -X22 * T
-            for (int t = wid; t < n_pairs * bpp; t += 4) {
-                const int pair = t / bpp, tt = t % bpp, ti = tt / bpd, tj = tt % bpd;
-                const int b = pair * 2 * s;
-                const float *px = x + (b + s + 16 * ti + l15) * LLD + b + s + lq;   // A[i][k] = X22[i][k]
-                const float *pt = sc + (pair * s + lq) * SLD + 16 * tj + l15;       // B[k][j] = T[k][j]
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < s; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-px[k], pt[k * SLD], acc, 0, 0, 0);
-                float *dst = x + (b + s + 16 * ti + 4 * lq) * LLD + b + 16 * tj + l15;
-                dst[0] = acc[0]; dst[LLD] = acc[1]; dst[2 * LLD] = acc[2]; dst[3 * LLD] = acc[3];
-            }
-            __syncthreads();
-            LF_ADD(5);
         }
-    }
+        __syncthreads();
+        LF_ADD(4);
+        // pass 2: X21 = -X22 * T.  The wave owns block column `mine`: its T fragments serve all block rows ti, and
+        // X22 is lower triangular, so row ti only needs k < 16 (ti + 1).
+        {
+            float bt[nq], ax[bpd][nq];
+            const float *pt = sc + (pair * s + lq) * SLD + 16 * mine + l15;      // B[k][j] = T[k][j]
+#pragma unroll
+            for (int q = 0; q < nq; ++q) bt[q] = pt[4 * q * SLD];
+            static_for<0, bpd>([&](auto tic) {
+                constexpr int ti = decltype(tic)::value;
+                const float *px = x + (b + s + 16 * ti + l15) * LLD + b + s + lq;   // A[i][k] = X22[i][k]
+#pragma unroll
+                for (int q = 0; q < 4 * (ti + 1); ++q) ax[ti][q] = -px[4 * q];
+            });
+            f32x4 acc[bpd];
+#pragma unroll
+            for (int ti = 0; ti < bpd; ++ti) acc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, nq>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<q / 4, bpd>([&](auto tic) {
+                    constexpr int ti = decltype(tic)::value;
+                    acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[ti][q], bt[q], acc[ti], 0, 0, 0);
+                });
+            });
+#pragma unroll
+            for (int ti = 0; ti < bpd; ++ti) {
+                float *dst = x + (b + s + 16 * ti + 4 * lq) * LLD + b + 16 * mine + l15;
+                dst[0] = acc[ti][0]; dst[LLD] = acc[ti][1]; dst[2 * LLD] = acc[ti][2]; dst[3 * LLD] = acc[ti][3];
+            }
+        }
+        __syncthreads();
+        LF_ADD(5);
+    });
     for (int e = tid; e < NB * (NB / 4); e += 256) {
         const int r = e >> 5, c4 = (e & 31) * 4;
         *reinterpret_cast<f32x4 *>(linv + (o + r) * ld + o + c4) = lds4(x + r * LLD + c4);
     }
 #ifdef GQ_LEAF_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LF_ADD(6);
+    LF_ADD(0);
     if (g_leaf_trace && tid == 0 && o == 0)
-        for (int i = 0; i < 7; ++i) g_leaf_trace[i] = lf_acc[i];
+        for (int i = 0; i < 8; ++i) g_leaf_trace[i] = lf_acc[i];
 #endif
 }
 

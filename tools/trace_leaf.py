@@ -32,11 +32,11 @@ def run():
                                p(ws), ctypes.c_size_t(nbytes), ctypes.byref(tries), None)
     assert rc == 0
     T = [int(v) for v in trace.cpu()]
-    names = ["load", "(a) diagonal blocks", "(b) panels", "(c) trailing updates", "inverse pass 1", "inverse pass 2", "store"]
-    tot = sum(T[:7])
+    names = ["load + store", "(a) diagonal blocks: load + factorisation", "(b) panels", "(c1) next panel's columns", "inverse pass 1", "inverse pass 2", "(a) inverse of the diagonal block + writes", "(a) wait for (c2) on waves 1-3"]
+    tot = sum(T[:8])
     for n, v in zip(names, T):
-        print(f"{n:24s} {v:8d} cycles  {100.0 * v / tot:5.1f} %")
-    print(f"{'total':24s} {tot:8d} cycles")
+        print(f"{n:42s} {v:8d} cycles  {100.0 * v / tot:5.1f} %")
+    print(f"{'total':42s} {tot:8d} cycles")
 
 if __name__ == "__main__":
     build() if sys.argv[1:2] == ["build"] else run()
