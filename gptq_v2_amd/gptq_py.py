@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -123,7 +125,10 @@ class HessianHook:
 # update) that leaves most of the chip idle, so the Linears of a set run on separate HIP streams
 # and fill each other's gaps (measured on the Llama-2-7B block: 32.6 -> 27.4 ms).  Slicing the
 # rows of ONE Linear over streams does not pay: a slice's chain is barely shorter than the whole
-# layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1.
+# layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1 -- except for a set
+# of ONE Linear (o_proj, down_proj), whose chain has nobody to share the chip with: its rows go to the three
+# side streams as three slices (SINGLE_SLICES), and one slice's update GEMM runs beside another's block kernel
+# (column loops of a Llama-2-7B block 20.2 -> 19.4 ms; the levels do not change, rows are independent).
 # The opposite -- the rows of the set's Linears stacked into ONE column loop (bit for bit the same levels;
 # block launches of three times the workgroups, trailing updates of three times the tiles) -- was measured
 # too and is slower: 21.2 against 19.9 ms per Llama-2-7B block.  A stacked gate/up launch is 344 workgroups
@@ -136,6 +141,7 @@ class HessianHook:
 # recorded twice, no stream has a priority -- so it has no cycle whatever the queue mapping is.
 N_QUANT_STREAMS = 3
 ROW_SLICES = 1
+SINGLE_SLICES = int(os.environ.get("GQ_SINGLE_SLICES", "3"))
 MIN_SLICE_ROWS = 256
 _streams: dict = {}
 
@@ -228,7 +234,7 @@ def gptq_quant_set(
 
     main = torch.cuda.current_stream(device)
     side = _side_streams(device)
-    per_weight = 1 if scale_bits > 0 else ROW_SLICES   # the step of a group's scale grid is a maximum over all rows
+    per_weight = 1 if scale_bits > 0 else (SINGLE_SLICES if len(weights) == 1 else ROW_SLICES)   # the step of a group's scale grid is a maximum over all rows
 
     def enqueue():
         for st in side:
