@@ -99,14 +99,29 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict_
     }
 }
 
-// out[i][j] = h[perm[i]][perm[j]]
-__global__ void gather_kernel(const float *__restrict__ h, const int32_t *__restrict__ perm, int64_t c,
+// diag[i] = h[i][i] * s with the dead-feature fix of scale_kernel: all the sort needs, so that with
+// act-order the scaling itself can ride on the gather below instead of being a pass of its own
+__global__ void scaled_diag_kernel(const float *__restrict__ h, int64_t c, float s, float *__restrict__ diag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        float v = h[i * c + i] * s;
+        if (v == 0.0f) v = 1.0f;
+        diag[i] = v;
+    }
+}
+
+// out[i][j] = s * h[perm[i]][perm[j]], a zero on the diagonal replaced by 1 (gptq_py.py:43-44): the scaled
+// Hessian in act-order from the unscaled one in model order
+__global__ void gather_kernel(const float *__restrict__ h, const int32_t *__restrict__ perm, int64_t c, float s,
                               float *__restrict__ out)
 {
     const int64_t total = c * c;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c, col = i - r * c;
-        out[i] = h[(int64_t)perm[r] * c + perm[col]];
+        float v = h[(int64_t)perm[r] * c + perm[col]] * s;
+        if (r == col && v == 0.0f) v = 1.0f;
+        out[i] = v;
     }
 }
 
@@ -741,14 +756,18 @@ int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int
     GQ_REQUIRE(n_samples > 0, "%s: n_samples must be positive", who);
     GQ_REQUIRE(!act_order || (perm && perm_inv), "%s: act_order needs perm and perm_inv buffers", who);
     const int64_t cc = c * c;
-    hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, c, (float)(2.0 / n_samples), ws.diag);
+    const float scale = (float)(2.0 / n_samples);
+    if (act_order)   // the scaling rides on the gather: one pass over H less
+        hipLaunchKernelGGL(scaled_diag_kernel, dim3((unsigned)gq_cdiv(c, 256)), dim3(256), 0, stream, hessian, c, scale, ws.diag);
+    else
+        hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, c, scale, ws.diag);
     GQ_LAUNCH_CHECK();
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp, ws.fatal);
     GQ_LAUNCH_CHECK();
     if (act_order) {
         hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 64)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
         GQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, ws.t);
+        hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, scale, ws.t);
         GQ_LAUNCH_CHECK();
         GQ_HIP(hipMemcpyAsync(hessian, ws.t, (size_t)cc * 4, hipMemcpyDeviceToDevice, stream));
     }
