@@ -78,3 +78,16 @@ def test_hip_linear_is_the_replay_of_the_packed_layer(amd, gpu):
     assert float((y_dense.float() - y_packed.float()).abs().max()) <= 2e-3 * scale
     ref = torch.nn.functional.linear(x.double(), lin.weight.data.double())
     assert float((y_dense.double() - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_nt_rows_do_not_depend_on_the_token_count(amd, gpu, dtype):
+    """The rows of a small product (few tiles, a partly empty persistent grid, ragged last tile) equal the same
+    rows inside a large one bit for bit: an output element is one sum in one order whatever the tiling."""
+    gen = torch.Generator(device=gpu).manual_seed(11)
+    n, k = 4096 + 24, 1024
+    x = torch.randn(8192, k, generator=gen, device=gpu).to(dtype)
+    w = (torch.randn(n, k, generator=gen, device=gpu) * 0.05).to(dtype)
+    big = amd.ops.gemm_nt(x, w)                 # 32 x 17 tiles of 256 x 256
+    for m in (2048, 1000, 130):
+        assert torch.equal(amd.ops.gemm_nt(x[:m].contiguous(), w), big[:m])
