@@ -70,11 +70,26 @@ __device__ __forceinline__ float recip_rn(float b)
     return (float)(1.0 / (double)b);
 }
 
-// fast form, no branch: `bad` collects the operands the proof does not cover
-__device__ __forceinline__ float div_rn_fast(float a, float b, float rb, bool &bad)
+// fast form, no branch.  The operands the proof does not cover -- a dividend that is neither zero nor within
+// 2^-97 .. 2^93, a reciprocal that is NaN -- are found afterwards from three running extrema of the operands'
+// magnitudes taken as integers (four cheap instructions per division beside the chain; a comparison of the
+// exponent field with a zero test per operand cost twelve).
+struct DivRange {
+    unsigned mx = 0u;            // largest |a|
+    unsigned mn1 = 0xffffffffu;  // smallest |a| - 1 (unsigned: a zero wraps to the top and never wins)
+    unsigned rb = 0u;            // largest |rb| (a NaN lies above infinity)
+    __device__ __forceinline__ bool bad() const
+    {
+        return mx >= (221u << 23) || mn1 < (30u << 23) - 1u || rb > 0x7f800000u;
+    }
+};
+
+__device__ __forceinline__ float div_rn_fast(float a, float b, float rb, DivRange &seen)
 {
-    const unsigned e = (__float_as_uint(a) >> 23) & 0xffu;
-    bad |= ((e - 30u) > 190u && a != 0.0f) || (rb != rb);
+    const unsigned ai = __float_as_uint(a) & 0x7fffffffu;
+    seen.mx = max(seen.mx, ai);
+    seen.mn1 = min(seen.mn1, ai - 1u);
+    seen.rb = max(seen.rb, __float_as_uint(rb) & 0x7fffffffu);
     const float q0 = __fmul_rn(a, rb);
     const float rem = fmaf(-b, q0, a);
     return fmaf(rem, rb, q0);
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
         // FAST: divisions by fma from precomputed reciprocals, straight-line; else the plain ones
         auto walk = [&](auto fast_c) -> bool {
             constexpr bool FAST = decltype(fast_c)::value;
-            bool bad = false;
+            DivRange bad;
 #pragma unroll
             for (int i = 0; i < SUB; ++i) w[i] = wl[c0 + i][lane];
 #pragma unroll
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
                     else w[i2] = __fsub_rn(w[i2], __fmul_rn(nerr[i], uv));
                 }
             }
-            return bad;
+            return bad.bad();
         };
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(walk(std::true_type{})) != 0, 0)) walk(std::false_type{});
 #ifdef GQ_QB_TRACE
@@ -246,18 +261,38 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
             float *__restrict__ wb = wt + col0;
             uint8_t *__restrict__ q8 = (uint8_t *)q_out + col0;
             int16_t *__restrict__ q16 = (int16_t *)q_out + col0;
+            // one copy of the store code per wave with its columns as constants: with the wave as a run-time
+            // test inside the loop over the 16 columns every column cost a scalar branch and the flags were
+            // tested again for each (1.5k of a sub-block's 8k cycles)
+            auto store_columns = [&](auto wv_c) __attribute__((always_inline)) {
+                constexpr int W = decltype(wv_c)::value;
 #pragma unroll
-            for (int i = 0; i < SUB; ++i) {
-                if ((i & 3) != wv) continue;
-                const unsigned o = (unsigned)i * rt + (unsigned)r;
-                eb[o] = SEM == GQ_SEM_KERNEL ? -nerr[i] : nerr[i];
-                if (quant_t) qb[o] = deq[i];
-                if (write_back) wb[o] = w[i];
-                if (q_out) {
-                    if (q_is_u8) q8[o] = (uint8_t)qv[i];
-                    else q16[o] = (int16_t)(uint16_t)qv[i];
+                for (int i = W; i < SUB; i += 4) {
+                    const unsigned o = (unsigned)i * rt + (unsigned)r;
+                    eb[o] = SEM == GQ_SEM_KERNEL ? -nerr[i] : nerr[i];
                 }
-            }
+                if (quant_t) {
+#pragma unroll
+                    for (int i = W; i < SUB; i += 4) qb[(unsigned)i * rt + (unsigned)r] = deq[i];
+                }
+                if (write_back) {
+#pragma unroll
+                    for (int i = W; i < SUB; i += 4) wb[(unsigned)i * rt + (unsigned)r] = w[i];
+                }
+                if (q_out) {
+                    if (q_is_u8) {
+#pragma unroll
+                        for (int i = W; i < SUB; i += 4) q8[(unsigned)i * rt + (unsigned)r] = (uint8_t)qv[i];
+                    } else {
+#pragma unroll
+                        for (int i = W; i < SUB; i += 4) q16[(unsigned)i * rt + (unsigned)r] = (int16_t)(uint16_t)qv[i];
+                    }
+                }
+            };
+            if (wv == 0) store_columns(std::integral_constant<int, 0>{});
+            else if (wv == 1) store_columns(std::integral_constant<int, 1>{});
+            else if (wv == 2) store_columns(std::integral_constant<int, 2>{});
+            else store_columns(std::integral_constant<int, 3>{});
         }
 #ifdef GQ_QB_TRACE
         if (jb < 8) QB_TR(3 + jb * 4);
@@ -280,6 +315,8 @@ __global__ __launch_bounds__(256) void quant_block_kernel(
                 b1[sidx] = __uint_as_float(pr[1]);
             }
             const int cb_lo = (c0 + SUB) >> 5, n_cb = (bs + 31) >> 5;
+            // (two of a wave's tasks as one stream -- reads of both first, MFMA chains interleaved -- was measured
+            // slower: 2.4k against 1.75k cycles per sub-block)
             for (int t = wv; t < (n_cb - cb_lo) * 2; t += 4) {
                 const int cblk = cb_lo + (t >> 1), rb = t & 1;
                 f32x16 acc;
