@@ -615,6 +615,208 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GqSgemmArgs g, int ti
 #endif
 }
 
+// ---- 64x64 tiles with a K range of at most 128: the short products on the dependency chains ----
+// The panel and near-update products of the Cholesky factorisation and the near updates of the column loop
+// are 128 deep, a few hundred 64-tiles at most, and hundreds of them follow each other per decoder block:
+// what they cost is latency, not arithmetic (64 MFMAs per wave).  Here the whole K range of a tile -- up to
+// four 32-deep stages of both operands, 64 KiB -- is fetched by LDS-DMA at once, together with the tile of
+// C, so a tile is ONE memory round trip, then its MFMA chain with the fragment reads of the next pair of
+// sub-steps issued under the current pair, then the stores; no barrier inside.  Same images and swizzles as
+// the 128-tile kernel above (64 rows: a k-contiguous image is [64 rows][8 chunks], a row-contiguous one
+// [32 k][16 chunks] with the halves swapped on odd k), same k-ascending chain per element.
+constexpr int SS_OP_BYTES = 64 * 32 * 4;           // one operand image of one stage: 8 KiB
+constexpr int SS_STAGE_BYTES = 2 * SS_OP_BYTES;
+constexpr int SS_LDS_BYTES = 4 * SS_STAGE_BYTES;   // 64 KiB
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void sgemm_small_kernel(GqSgemmArgs g, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool A_KM = (LAYOUT & GQ_A_KM) != 0;
+    constexpr bool B_KN = (LAYOUT & GQ_B_KN) != 0;
+    constexpr int BT = 64;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    g.a += (int64_t)blockIdx.y * g.stride_a;
+    g.b += (int64_t)blockIdx.y * g.stride_b;
+    g.c += (int64_t)blockIdx.y * g.stride_c;
+    int tm, tn;
+    if (g.lower_only) {
+        const int bid = blockIdx.x;
+        int r = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= bid) ++r;
+        while (r * (r + 1) / 2 > bid) --r;
+        tm = r;
+        tn = bid - r * (r + 1) / 2;
+    } else {
+        tm = blockIdx.x / tiles_n;
+        tn = blockIdx.x % tiles_n;
+    }
+    const int m0 = tm * BT, n0 = tn * BT;
+    // the K range of the tile (one operand triangular), cut at the tile's own edge
+    int k_lo = 0, k_hi = g.k;
+    if (g.trim == GQ_TRIM_K_LE_N) k_hi = min(g.k, (tn + 1) * BT);
+    else if (g.trim == GQ_TRIM_K_GE_N) k_lo = min(g.k, tn * BT);
+    else if (g.trim == GQ_TRIM_K_LE_M) k_hi = min(g.k, (tm + 1) * BT);
+    const int n_steps = (k_hi - k_lo) / BKS;   // 0..4 (the host checks k <= 128)
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // everything the tile needs in one go: the pieces of all stages, then the tile of C
+    {
+        const char *ua = reinterpret_cast<const char *>(A_KM ? g.a + (int64_t)k_lo * g.lda + m0 : g.a + (int64_t)m0 * g.lda + k_lo);
+        const char *ub = reinterpret_cast<const char *>(B_KN ? g.b + (int64_t)k_lo * g.ldb + n0 : g.b + (int64_t)n0 * g.ldb + k_lo);
+        const int64_t inc_a = (A_KM ? (int64_t)BKS * g.lda : (int64_t)BKS) * 4, inc_b = (B_KN ? (int64_t)BKS * g.ldb : (int64_t)BKS) * 4;
+        unsigned voff_a[2], voff_b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = wave * 2 + j;   // piece 0..7 of an 8 KiB image
+            if constexpr (A_KM) {
+                const int k = 4 * p + (lane >> 4), q = (lane & 15) ^ (8 * (k & 1));
+                voff_a[j] = (unsigned)(((int64_t)k * g.lda + 4 * q) * 4);
+            } else {
+                const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                voff_a[j] = (unsigned)(((int64_t)row * g.lda + 4 * c) * 4);
+            }
+            if constexpr (B_KN) {
+                const int k = 4 * p + (lane >> 4), q = (lane & 15) ^ (8 * (k & 1));
+                voff_b[j] = (unsigned)(((int64_t)k * g.ldb + 4 * q) * 4);
+            } else {
+                const int row = 8 * p + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+                voff_b[j] = (unsigned)(((int64_t)row * g.ldb + 4 * c) * 4);
+            }
+        }
+        for (int st = 0; st < n_steps; ++st) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(ua + voff_a[j]),
+                                                 GQ_LDS_PTR(void, smem_raw + st * SS_STAGE_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GQ_GLOBAL_PTR(ub + voff_b[j]),
+                                                 GQ_LDS_PTR(void, smem_raw + st * SS_STAGE_BYTES + SS_OP_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+            }
+            ua += inc_a;
+            ub += inc_b;
+        }
+    }
+    f32x16 acc;
+    if (g.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int col = n0 + wc * 32 + li;
+            acc[e] = g.c[(int64_t)row * g.ldc + col];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    }
+    const float sgn = g.negate ? -1.0f : 1.0f;
+
+    const unsigned lds_base = (unsigned)(uintptr_t)GQ_LDS_PTR(char, smem_raw);
+    unsigned addr_a[A_KM ? 1 : 8], addr_b[B_KN ? 1 : 8];
+    if constexpr (A_KM) {
+        const int r = wr * 32 + li;
+        addr_a[0] = lds_base + lh * 256 + ((((unsigned)r >> 2) ^ (8u * lh)) << 4) + ((r & 3) << 2);
+    } else {
+        const int r = wr * 32 + li;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) addr_a[c] = lds_base + r * 128 + lh * 4 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    if constexpr (B_KN) {
+        const int r = wc * 32 + li;
+        addr_b[0] = lds_base + SS_OP_BYTES + lh * 256 + ((((unsigned)r >> 2) ^ (8u * lh)) << 4) + ((r & 3) << 2);
+    } else {
+        const int r = wc * 32 + li;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) addr_b[c] = lds_base + SS_OP_BYTES + r * 128 + lh * 4 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    float fa[2][2], fb[2][2];   // [set][sub-step of the pair]
+    auto frag_read = [&](auto st_c, auto c_c, auto set_c, auto i_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_c)::value, C = decltype(c_c)::value, SET = decltype(set_c)::value, I = decltype(i_c)::value;
+        constexpr int OP = I >> 1, SUB = I & 1;
+        if constexpr (OP == 0) {
+            if constexpr (A_KM) sg_read_b32<ST * SS_STAGE_BYTES + (2 * C + SUB) * 512>(fa[SET][SUB], addr_a[0]);
+            else sg_read_b32<ST * SS_STAGE_BYTES + SUB * 8>(fa[SET][SUB], addr_a[C]);
+        } else {
+            if constexpr (B_KN) sg_read_b32<ST * SS_STAGE_BYTES + (2 * C + SUB) * 512>(fb[SET][SUB], addr_b[0]);
+            else sg_read_b32<ST * SS_STAGE_BYTES + SUB * 8>(fb[SET][SUB], addr_b[C]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (the loads of C are older: they are in too)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (n_steps > 0) {
+        sg_for<0, 4>([&](auto i) { frag_read(I0{}, I0{}, I0{}, i); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // stage ST; MORE: another stage follows (its first fragments are read under this stage's last pair)
+    auto k_step = [&](auto st_c, auto more_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
+        sg_for<0, 8>([&](auto c_c) {
+            constexpr int C = decltype(c_c)::value;
+            constexpr int SET = C & 1;
+            using NSET = std::integral_constant<int, SET ^ 1>;
+            fa[SET][0] *= sgn;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][0], fb[SET][0], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fa[SET][1] *= sgn;
+            sg_for<0, 4>([&](auto i_c) {
+                if constexpr (C < 7) frag_read(st_c, std::integral_constant<int, (C + 1) & 7>{}, NSET{}, i_c);
+                else if constexpr (MORE) frag_read(std::integral_constant<int, (ST + 1) & 3>{}, I0{}, NSET{}, i_c);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][1], fb[SET][1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (C < 7 || MORE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        if (n_steps == 4) { k_step(I0{}, T{}); k_step(I1{}, T{}); k_step(I2{}, T{}); k_step(I3{}, F{}); }
+        else if (n_steps == 3) { k_step(I0{}, T{}); k_step(I1{}, T{}); k_step(I2{}, F{}); }
+        else if (n_steps == 2) { k_step(I0{}, T{}); k_step(I1{}, F{}); }
+        else if (n_steps == 1) { k_step(I0{}, F{}); }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int col = n0 + wc * 32 + li;
+        g.c[(int64_t)row * g.ldc + col] = acc[e];
+    }
+}
+
+int launch_sgemm_small(const GqSgemmArgs &args, hipStream_t stream)
+{
+    const int tiles_m = args.m / 64, tiles_n = args.n / 64;
+    GQ_REQUIRE(!args.lower_only || tiles_m == tiles_n, "sgemm: lower_only needs a square tile grid");
+    const int n_blocks = args.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    void (*kern)(GqSgemmArgs, int, int) = nullptr;
+    switch (args.layout) {
+    case GQ_A_MK | GQ_B_NK: kern = sgemm_small_kernel<GQ_A_MK | GQ_B_NK>; break;
+    case GQ_A_MK | GQ_B_KN: kern = sgemm_small_kernel<GQ_A_MK | GQ_B_KN>; break;
+    case GQ_A_KM | GQ_B_NK: kern = sgemm_small_kernel<GQ_A_KM | GQ_B_NK>; break;
+    case GQ_A_KM | GQ_B_KN: kern = sgemm_small_kernel<GQ_A_KM | GQ_B_KN>; break;
+    default: GQ_REQUIRE(false, "sgemm: bad layout %d", args.layout);
+    }
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SS_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(n_blocks, std::max(args.batch, 1)), dim3(256), SS_LDS_BYTES, stream, args, tiles_m, tiles_n);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 int launch_sgemm_dma(const GqSgemmArgs &args, hipStream_t stream)
 {
     const int tiles_m = args.m / 128, tiles_n = args.n / 128;
@@ -684,15 +886,18 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream)
     GQ_REQUIRE(args.batch <= 1 || (args.stride_a % 4 == 0 && args.stride_b % 4 == 0 && args.stride_c % 4 == 0),
                "sgemm: batch strides must be multiples of 4");
     const int64_t blocks128 = (args.lower_only ? tm * (tm + 1) / 2 : tm * tn) * std::max(args.batch, 1);
-    if (blocks128 < 256) return launch_sgemm<64>(args, stream);
-    // whole 128-tiles, whole k-steps, lane offsets of the DMA within 32 bits: the hand-scheduled kernel
     static const bool plain_env = [] { const char *e = getenv("GQ_SGEMM"); return e && e[0] == 'p'; }();
     const bool plain = plain_env || g_sgemm_plain;
     const int64_t span_a = (args.layout & GQ_A_KM) ? 32 * args.lda + 128 : 128 * args.lda + 32;
     const int64_t span_b = (args.layout & GQ_B_KN) ? 32 * args.ldb + 128 : 128 * args.ldb + 32;
-    if (!plain && args.m % 128 == 0 && args.n % 128 == 0 && args.k % BKS == 0 && span_a < ((int64_t)1 << 29) &&
-        span_b < ((int64_t)1 << 29))
-        return launch_sgemm_dma(args, stream);
+    const bool dma_ok = !plain && args.k % BKS == 0 && span_a < ((int64_t)1 << 29) && span_b < ((int64_t)1 << 29);
+    if (blocks128 < 256) {
+        // short products (K <= 128) of whole 64-tiles: everything of a tile in one memory round trip
+        if (dma_ok && args.k <= 128 && args.m % 64 == 0 && args.n % 64 == 0) return launch_sgemm_small(args, stream);
+        return launch_sgemm<64>(args, stream);
+    }
+    // whole 128-tiles, whole k-steps, lane offsets of the DMA within 32 bits: the hand-scheduled kernel
+    if (dma_ok && args.m % 128 == 0 && args.n % 128 == 0) return launch_sgemm_dma(args, stream);
     return launch_sgemm<128>(args, stream);
 }
 

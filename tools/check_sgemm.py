@@ -13,7 +13,11 @@ for layout in range(4):
     for trim, negate, acc, lower, pad, batch, (m, n, k) in [
             (0, 0, 0, 0, 0, 1, (2048, 2048, 64)), (0, 1, 1, 0, 0, 1, (2048, 2560, 96)), (1, 0, 1, 0, 0, 1, (2048, 2048, 2048)),
             (2, 1, 0, 0, 0, 1, (2048, 2048, 2048)), (3, 0, 0, 0, 0, 1, (2048, 2048, 2048)), (0, 1, 1, 1, 0, 1, (3072, 3072, 160)),
-            (0, 0, 1, 0, 8, 1, (2048, 2304, 128)), (0, 1, 0, 0, 4, 3, (1280, 1280, 256)), (0, 0, 1, 0, 0, 1, (2048, 2048, 32))]:
+            (0, 0, 1, 0, 8, 1, (2048, 2304, 128)), (0, 1, 0, 0, 4, 3, (1280, 1280, 256)), (0, 0, 1, 0, 0, 1, (2048, 2048, 32)),
+            # short products on 64-tiles (fewer than 256 tiles of 128): one round trip per tile
+            (0, 1, 1, 0, 0, 1, (1024, 384, 128)), (1, 0, 0, 0, 0, 1, (1984, 128, 128)), (2, 0, 1, 0, 0, 1, (960, 128, 128)),
+            (3, 1, 0, 0, 0, 1, (128, 1024, 128)), (0, 1, 1, 1, 0, 1, (768, 768, 96)), (0, 0, 1, 0, 12, 5, (192, 320, 64)),
+            (0, 1, 1, 0, 0, 1, (64, 64, 32))]:
         g = torch.Generator(device="cpu").manual_seed(layout * 100 + trim * 10 + negate)
         ra, ca = ((k, m) if layout & 1 else (m, k))
         rb, cb = ((k, n) if layout & 2 else (n, k))
