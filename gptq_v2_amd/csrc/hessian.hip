@@ -64,10 +64,13 @@ __global__ void damp_kernel(const float *__restrict__ diag, int64_t c, float rat
 // The order is total: a NaN counts as smaller than every number and equal to another NaN, so the
 // ranks are a permutation whatever the diagonal holds (with the plain comparisons every NaN would
 // get the same rank, slots of perm would stay unwritten and the gather behind it would read out
-// of bounds).  A workgroup ranks 64 elements; its four waves each count one quarter of every
-// 1024-value chunk.
-__global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ perm,
-                                                        int32_t *__restrict__ perm_inv)
+// of bounds).  A workgroup ranks 64 elements against one of RANK_SPLIT slices of the diagonal -- its
+// four waves each count one quarter of every 1024-value chunk of the slice -- and adds its count to
+// rank[i] (integer atomics: the sum does not depend on their order); rank starts at zero and is
+// perm_inv when all slices are in, and perm_scatter_kernel inverts it.
+constexpr int RANK_SPLIT = 4;
+
+__global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict__ diag, int c, int32_t *__restrict__ rank_out)
 {
     __shared__ float chunk[1024];
     __shared__ int part[4][64];
@@ -75,11 +78,13 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict_
     const int i = blockIdx.x * 64 + tx;
     const float di = i < c ? diag[i] : 0.0f;
     const bool nan_i = di != di;
+    const int per = (((c + RANK_SPLIT - 1) / RANK_SPLIT) + 1023) / 1024 * 1024;   // slice length, whole chunks
+    const int j_lo = blockIdx.y * per, j_hi = min(c, j_lo + per);
     int rank = 0;
-    for (int base = 0; base < c; base += 1024) {
-        for (int t = threadIdx.x; t < 1024; t += 256) chunk[t] = base + t < c ? diag[base + t] : 0.0f;
+    for (int base = j_lo; base < j_hi; base += 1024) {
+        for (int t = threadIdx.x; t < 1024; t += 256) chunk[t] = base + t < j_hi ? diag[base + t] : 0.0f;
         __syncthreads();
-        const int lo = q * 256, lim = min(lo + 256, c - base);
+        const int lo = q * 256, lim = min(lo + 256, j_hi - base);
 #pragma unroll 8
         for (int t = lo; t < lim; ++t) {
             const float dj = chunk[t];
@@ -94,9 +99,14 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float *__restrict_
     __syncthreads();
     if (q == 0 && i < c) {
         rank = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
-        perm[rank] = i;
-        perm_inv[i] = rank;
+        if (rank) atomicAdd(rank_out + i, rank);
     }
+}
+
+__global__ void perm_scatter_kernel(const int32_t *__restrict__ perm_inv, int c, int32_t *__restrict__ perm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) perm[perm_inv[i]] = i;
 }
 
 // diag[i] = h[i][i] * s with the dead-feature fix of scale_kernel: all the sort needs, so that with
@@ -765,7 +775,10 @@ int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(256), 0, stream, ws.diag, c, damp_ratio, ws.damp, ws.fatal);
     GQ_LAUNCH_CHECK();
     if (act_order) {
-        hipLaunchKernelGGL(rank_sort_kernel, dim3((int)gq_cdiv(c, 64)), dim3(256), 0, stream, ws.diag, (int)c, perm, perm_inv);
+        GQ_HIP(hipMemsetAsync(perm_inv, 0, (size_t)c * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)gq_cdiv(c, 64), RANK_SPLIT), dim3(256), 0, stream, ws.diag, (int)c, perm_inv);
+        GQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(perm_scatter_kernel, dim3((unsigned)gq_cdiv(c, 256)), dim3(256), 0, stream, perm_inv, (int)c, perm);
         GQ_LAUNCH_CHECK();
         hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, scale, ws.t);
         GQ_LAUNCH_CHECK();
@@ -782,13 +795,16 @@ int invert_try(const InvertWorkspace &ws, float *hessian, float *hessian_inv, in
     const int64_t cp = gq_round_up(c, NB);
     GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
     GQ_HIP(hipMemsetAsync(ws.status, 0, 256, stream));
-    GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
     hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
     GQ_LAUNCH_CHECK();
     static const bool recursive = [] {   // experiments: GQ_INVERT=rec selects the recursive form
         const char *e = getenv("GQ_INVERT");
         return e && e[0] == 'r';
     }();
+    // linv is not cleared for the panel form: the leaves write their diagonal blocks whole, every block below
+    // them is written before it is read, and nothing -- the products' K trims, the flip into U -- reads above
+    // the block diagonal (checked by running the GPU tests with linv filled with NaN)
+    if (recursive) GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
     int rc = recursive ? cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream)
                        : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream);
     if (rc) return rc;
