@@ -106,6 +106,8 @@ __device__ __forceinline__ float div_rn_fast(float a, float b, float rb, DivRang
 // over the waves SUB columns at a time.  Every weight still sees its updates in ascending column
 // order, one fma each, so the cut into sub-blocks does not change any bit.
 constexpr int ULD = QB + 4;   // stride of the U square in LDS
+// (Shrinking this to 96 KiB -- no padding, the reciprocals in registers -- so that a workgroup fits on a CU beside
+// one 64 KiB workgroup of another slice's update GEMM was measured: column loops of a block 16.7 -> 17.8 ms.)
 constexpr int QB_LDS = (QB * 64 + QB * ULD + QB) * 4;   // weights, U square, reciprocals of its diagonal
 
 #ifdef GQ_QB_TRACE
