@@ -94,3 +94,39 @@ def test_dropin_modules_carry_the_references_public_names():
     q = quant.Quantizer()
     for name in ("find_params", "mse", "quantize", "dequantize", "dequantize_quantized"):
         assert callable(getattr(q, name)), name
+
+
+def test_quantlinear_concat_and_expand_policy_on_cpu():
+    """Host logic of the packed layer that needs no GPU: which token counts take the expand-once forward, and
+    that a concatenation stacks the packed words, scales and zero points of its parts row-wise and refuses
+    parts that do not share input width, act-order or storage."""
+    import torch
+    from gptq_v2_amd.quant import QuantLinear
+
+    def fake(rows, c=256, group=128, perm=None, dense3=False):
+        layer = QuantLinear(c, rows, group, 3 if dense3 else 4, torch.float16, dense3=dense3)
+        layer.qweight = torch.randint(0, 2 ** 31 - 1, (c // 64, rows, 6 if dense3 else 8), dtype=torch.int32)
+        layer.scales = torch.rand(c // group, rows).half()
+        layer.qzeros = torch.randint(0, 16, (c // group, rows), dtype=torch.uint8)
+        layer.perm = perm
+        return layer
+
+    small, big = fake(4096), fake(8192)
+    least = QuantLinear.expand_min_tokens
+    assert least > 0
+    assert big._expands(least) and not big._expands(least - 1)
+    assert small._expands(2 * least) and not small._expands(2 * least - 1)
+    small.expand_min_tokens = 0
+    assert not small._expands(1 << 20)
+
+    perm = torch.randperm(256).to(torch.int32)
+    parts = [fake(64, perm=perm), fake(32, perm=perm), fake(96, perm=perm)]
+    fused = QuantLinear.concat(parts)
+    assert fused.out_features == 192 and fused.in_features == 256 and fused.perm is perm
+    assert torch.equal(fused.qweight[:, 64:96], parts[1].qweight) and torch.equal(fused.scales[:, 96:], parts[2].scales)
+    assert torch.equal(fused.qzeros[:, :64], parts[0].qzeros) and fused.qweight.is_contiguous()
+    import pytest
+    for other in (fake(64, c=128, perm=perm[:128].contiguous()), fake(64, perm=torch.roll(perm, 1)), fake(64, perm=None),
+                  fake(64, group=64, perm=perm), fake(64, perm=perm, dense3=True)):
+        with pytest.raises(ValueError):
+            QuantLinear.concat([parts[0], other])
