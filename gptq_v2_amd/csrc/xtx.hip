@@ -25,15 +25,59 @@
 #include <string.h>
 
 #include <algorithm>
-#include <mutex>
 #include <type_traits>
-#include <vector>
 
 #include "gq_common.h"
 
 namespace {
 
 constexpr int TM = 128;        // output tile edge
+
+// Tile order: the (lower triangle of the) nt x nt tile grid cut into S x S super-tiles, super-tiles
+// row-major, tiles row-major inside each; position `pos` of that order -> (tile row, tile column).
+// Computed by every workgroup for itself (a loop over at most nt / S super-rows of scalar arithmetic):
+// no table in device memory, so the library allocates nothing.  order = nt | S << 16 | lower << 24.
+__host__ __device__ __forceinline__ uint32_t xtx_order(int nt, int super, int lower)
+{
+    return (uint32_t)nt | ((uint32_t)super << 16) | ((uint32_t)(lower != 0) << 24);
+}
+
+__host__ __device__ __forceinline__ void xtx_tile_of(int pos, uint32_t order, int &ti, int &tj)
+{
+    const int nt = (int)(order & 0xffffu), S = (int)((order >> 16) & 0xffu);
+    const bool lower = (order >> 24) != 0;
+    const int ns = (nt + S - 1) / S;
+    ti = tj = 0;
+    for (int si = 0; si < ns; ++si) {
+        const int rows = nt - si * S < S ? nt - si * S : S;
+        // super-row si: `full` tiles in complete super-tiles left of the diagonal one (all super-tiles but the
+        // last of the row when the whole grid is wanted), then the diagonal (or last) super-tile
+        const int n_full = lower ? si : ns - 1;
+        const int full = n_full * rows * S;
+        const int last_cols = lower ? rows : nt - (ns - 1) * S;
+        const int last = lower ? rows * (rows + 1) / 2 : rows * last_cols;
+        if (pos < full + last) {
+            if (pos < full) {
+                const int sj = pos / (rows * S), rem = pos - sj * rows * S;
+                ti = si * S + rem / S;
+                tj = sj * S + rem % S;
+            } else {
+                pos -= full;
+                if (lower) {
+                    int r = 0;
+                    while ((r + 1) * (r + 2) / 2 <= pos) ++r;
+                    ti = si * S + r;
+                    tj = si * S + pos - r * (r + 1) / 2;
+                } else {
+                    ti = si * S + pos / last_cols;
+                    tj = n_full * S + pos % last_cols;
+                }
+            }
+            return;
+        }
+        pos -= full + last;
+    }
+}
 
 // One operand tile (BKT tokens x 128 columns of 16-bit) into LDS by LDS-DMA: BKT/4 wave-instructions
 // of 1 KiB (= 4 token rows), BKT/16 per wave.  LDS position P (bytes) holds
@@ -124,7 +168,7 @@ __device__ __forceinline__ void tile_of_block(int bid, int nt, int lower, int &t
 // (counted vmcnt), then the barrier makes every wave's share visible.
 template <int DTYPE, int BKT, int NST>
 __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
-                                                       int hidden, int n_ktiles, const uint32_t *__restrict__ tile_table,
+                                                       int hidden, int n_ktiles, uint32_t tile_order,
                                                        int n_blocks, int mirror)
 {
     constexpr int OP_BYTES = BKT * TM * 2;
@@ -147,8 +191,8 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
         const int q = n_blocks >> 3, r = n_blocks & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const uint32_t packed_tile = tile_table[bid];
-    const int ti = (int)(packed_tile >> 16), tj = (int)(packed_tile & 0xffffu);
+    int ti, tj;
+    xtx_tile_of(bid, tile_order, ti, tj);
     const int m0 = ti * TM, n0 = tj * TM;
     const int64_t ld = hidden;
 
@@ -312,7 +356,7 @@ __device__ unsigned long long *g_xtx_trace = nullptr;
 
 template <int DTYPE>
 __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
-                                                     int hidden, int n_ktiles_all, const uint32_t *__restrict__ tile_table,
+                                                     int hidden, int n_ktiles_all, uint32_t tile_order,
                                                      int n_blocks, int mirror, int n_tiles, int n_splits, int64_t part_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -334,8 +378,8 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     // token split: workgroup (tile, split) adds the products of its share of the k-steps into partial
     // Hessian `split` (part_stride floats apart); the caller sums the parts
     const int split = bid / n_tiles;
-    const uint32_t packed_tile = tile_table[bid - split * n_tiles];
-    const int ti = (int)(packed_tile >> 16), tj = (int)(packed_tile & 0xffffu);
+    int ti, tj;
+    xtx_tile_of(bid - split * n_tiles, tile_order, ti, tj);
     const int m0 = ti * T2, n0 = tj * T2;
     const int64_t ld = hidden;
     const int k_begin = (int)((int64_t)n_ktiles_all * split / n_splits);
@@ -566,41 +610,14 @@ __global__ __launch_bounds__(256) void xtx_generic_kernel(float *__restrict__ he
         }
 }
 
-// Tile order: the (lower triangle of the) nt x nt tile grid cut into SUPER x SUPER super-tiles,
-// super-tiles row-major, tiles row-major inside each.  Entry = (tile_row << 16) | tile_col.
-struct TileTable {
-    int device, nt, lower, super, n_blocks;
-    uint32_t *dev;
-};
-
-int get_tile_table(int nt, int lower, int SUPER_TILE, const uint32_t **out, int *n_blocks_out)
+// super-tile edge of the tile order (experiment knob: GQ_XTX_SUPERTILE) and the number of tiles
+int xtx_super_tile(int by_default)
 {
-    if (const char *e = getenv("GQ_XTX_SUPERTILE")) SUPER_TILE = std::max(1, atoi(e));   // experiment knob
-    static std::mutex mu;
-    static std::vector<TileTable> cache;
-    int device = 0;
-    GQ_HIP(hipGetDevice(&device));
-    std::lock_guard<std::mutex> lock(mu);
-    for (const TileTable &t : cache)
-        if (t.device == device && t.nt == nt && t.lower == lower && t.super == SUPER_TILE) {
-            *out = t.dev;
-            *n_blocks_out = t.n_blocks;
-            return GQ_OK;
-        }
-    std::vector<uint32_t> host;
-    const int ns = (nt + SUPER_TILE - 1) / SUPER_TILE;
-    for (int si = 0; si < ns; ++si)
-        for (int sj = 0; sj < (lower ? si + 1 : ns); ++sj)
-            for (int ti = si * SUPER_TILE; ti < std::min(nt, (si + 1) * SUPER_TILE); ++ti)
-                for (int tj = sj * SUPER_TILE; tj < std::min(nt, (sj + 1) * SUPER_TILE); ++tj)
-                    if (!lower || tj <= ti) host.push_back(((uint32_t)ti << 16) | (uint32_t)tj);
-    TileTable t{device, nt, lower, SUPER_TILE, (int)host.size(), nullptr};
-    GQ_HIP(hipMalloc((void **)&t.dev, host.size() * sizeof(uint32_t)));
-    GQ_HIP(hipMemcpy(t.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    cache.push_back(t);
-    *out = t.dev;
-    *n_blocks_out = t.n_blocks;
-    return GQ_OK;
+    static const int forced = [] {
+        const char *e = getenv("GQ_XTX_SUPERTILE");
+        return e ? std::max(1, std::min(255, atoi(e))) : 0;
+    }();
+    return forced ? forced : by_default;
 }
 
 template <int DTYPE, int BKT, int NST>
@@ -610,10 +627,9 @@ int launch_mfma(float *hess, const unsigned short *x, int64_t n_tokens, int64_t 
     constexpr int LDS = NST * 2 * BKT * TM * 2;
     const int nt = (int)(hidden / TM);
     const int n_ktiles = (int)(n_tokens / BKT);
-    const uint32_t *table = nullptr;
-    int n_blocks = 0;
-    int rc = get_tile_table(nt, compute_lower_only, 12, &table, &n_blocks);
-    if (rc) return rc;
+    GQ_REQUIRE(nt < 65536, "gq_xtx_accumulate: hidden size too large");
+    const int n_blocks = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
+    const uint32_t table = xtx_order(nt, xtx_super_tile(12), compute_lower_only);
     GQ_HIP(hipFuncSetAttribute((const void *)xtx_mfma_kernel<DTYPE, BKT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     hipLaunchKernelGGL((xtx_mfma_kernel<DTYPE, BKT, NST>), dim3(n_blocks), dim3(256), LDS, stream, hess, x, (int)hidden,
                        n_ktiles, table, n_blocks, mirror);
@@ -628,12 +644,11 @@ int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64
 {
     const int nt = (int)(hidden / T2);
     const int n_ktiles = (int)(n_tokens / BK2);
-    const uint32_t *table = nullptr;
-    int n_blocks = 0;
+    GQ_REQUIRE(nt < 65536, "gq_xtx_accumulate: hidden size too large");
+    const int n_blocks = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
     // 6 x 6 super-tiles: the ~32 tiles an XCD runs at a time (one per CU) then span about 12 column
     // panels of X instead of 64, and the XCD's L2 serves the rest (measured: fewest memory-side bytes)
-    int rc = get_tile_table(nt, compute_lower_only, 6, &table, &n_blocks);
-    if (rc) return rc;
+    const uint32_t table = xtx_order(nt, xtx_super_tile(6), compute_lower_only);
     auto kern = xtx256_kernel<DTYPE>;
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
     hipLaunchKernelGGL(kern, dim3(n_blocks * n_splits), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles, table,

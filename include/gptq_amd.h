@@ -52,8 +52,7 @@ int gq_version(void);
  * compute_lower_only != 0: only tiles on or below the diagonal are computed; unless
  * save_lower_only != 0 each strictly-lower tile is also written, transposed, to its mirror
  * position, so H comes out exactly symmetric.  save_lower_only requires compute_lower_only.
- * The first call for a given (device, hidden, compute_lower_only) allocates the tile-order table of that
- * grid with hipMalloc (at most 64 KiB, kept until the process ends); later calls allocate nothing.
+ * Allocates nothing (the order in which workgroups take the tiles is computed in the kernel).
  * ref: package/gptq/__init__.py:6-13, accumulate_hessian.cpp:20-45,
  *      accumulate_hessian_kernel.cu:10-84 (full product: compute_lower_only = 0),
  *      gptq_triton/accumulate_hessian.py:134-149 (save_lower_only / compute_lower_only). */
