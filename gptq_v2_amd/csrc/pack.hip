@@ -131,22 +131,59 @@ __device__ __forceinline__ unsigned short deq16(int q, int z, unsigned short s_r
     }
 }
 
-// One workgroup per row: the row of q (C bytes) is staged in LDS, then out[r][j] = deq(q[perm_inv[j]]).
+// One workgroup per DQ_ROWS rows: their levels (C bytes each), scales and zero points are staged in LDS, then
+// out[r][j] = deq(q[r][perm_inv[j]]), eight columns per thread and pass with one 16-byte store per row.  The
+// permutation entry and the group of a column are looked up once for all rows of the workgroup (they were a
+// 4-byte load and a 64-bit division per ELEMENT: more traffic than the weights themselves).
+constexpr int DQ_ROWS = 4;
+
 template <int DTYPE>
 __global__ __launch_bounds__(256) void dequant_kernel(const uint8_t *__restrict__ q, const unsigned short *__restrict__ scale,
                                                       const uint8_t *__restrict__ zero, const int32_t *__restrict__ perm_inv,
-                                                      int64_t c, int n_groups, int group_size,
+                                                      int64_t r_total, int64_t c, int n_groups, int group_size,
                                                       const int32_t *__restrict__ col_group, unsigned short *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint8_t *qrow = (uint8_t *)smem;
-    const int64_t r = blockIdx.x;
-    for (int64_t j = threadIdx.x; j < c; j += 256) qrow[j] = q[r * c + j];
+    const int ci = (int)c, cpad = (ci + 15) & ~15;
+    uint8_t *qrow = (uint8_t *)smem;                                           // [DQ_ROWS][cpad]
+    unsigned short *srow = (unsigned short *)(smem + DQ_ROWS * cpad);          // [DQ_ROWS][n_groups]
+    uint8_t *zrow = (uint8_t *)(srow + DQ_ROWS * n_groups);                    // [DQ_ROWS][n_groups]
+    const int64_t r0 = (int64_t)blockIdx.x * DQ_ROWS;
+    const int rows = (int)min((int64_t)DQ_ROWS, r_total - r0);
+    for (int i = 0; i < rows; ++i) {
+        for (int j = threadIdx.x; j < ci; j += 256) qrow[i * cpad + j] = q[(r0 + i) * c + j];
+        for (int g = threadIdx.x; g < n_groups; g += 256) {
+            srow[i * n_groups + g] = scale[(r0 + i) * n_groups + g];
+            zrow[i * n_groups + g] = zero[(r0 + i) * n_groups + g];
+        }
+    }
     __syncthreads();
-    for (int64_t j = threadIdx.x; j < c; j += 256) {
-        const int64_t k = perm_inv ? perm_inv[j] : j;
-        const int g = group_size > 0 ? (int)(k / group_size) : col_group[k];
-        out[r * c + j] = deq16<DTYPE>(qrow[k], zero[r * n_groups + g], scale[r * n_groups + g]);
+    const bool wide = (ci & 7) == 0 && (((uintptr_t)out) & 15) == 0;
+    if (wide) {
+        for (int j0 = threadIdx.x * 8; j0 < ci; j0 += 256 * 8) {
+            int k[8], g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                k[e] = perm_inv ? perm_inv[j0 + e] : j0 + e;
+                g[e] = group_size > 0 ? k[e] / group_size : col_group[k[e]];
+            }
+            for (int i = 0; i < rows; ++i) {
+                unsigned short h[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = deq16<DTYPE>(qrow[i * cpad + k[e]], zrow[i * n_groups + g[e]], srow[i * n_groups + g[e]]);
+                u32x4 o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = (unsigned)h[2 * w] | ((unsigned)h[2 * w + 1] << 16);
+                *reinterpret_cast<u32x4 *>(out + (r0 + i) * c + j0) = o;
+            }
+        }
+    } else {
+        for (int j = threadIdx.x; j < ci; j += 256) {
+            const int k = perm_inv ? perm_inv[j] : j;
+            const int g = group_size > 0 ? k / group_size : col_group[k];
+            for (int i = 0; i < rows; ++i)
+                out[(r0 + i) * c + j] = deq16<DTYPE>(qrow[i * cpad + k], zrow[i * n_groups + g], srow[i * n_groups + g]);
+        }
     }
 }
 
@@ -337,17 +374,17 @@ extern "C" int gq_dequantize(const uint8_t *qweight, const void *scale, const ui
     GQ_REQUIRE(qweight && scale && qzero && weight_out, "gq_dequantize: NULL pointer");
     GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_dequantize: bad dtype %d", dtype);
     GQ_REQUIRE(r > 0 && c > 0 && n_groups > 0, "gq_dequantize: bad shape");
-    GQ_REQUIRE(c <= 160 * 1024, "gq_dequantize: a row of %lld columns does not fit in LDS", (long long)c);
+    GQ_REQUIRE(DQ_ROWS * (c + 16 + 3 * (int64_t)n_groups) + 32 <= 160 * 1024, "gq_dequantize: %d rows of %lld columns in %d groups do not fit in LDS", DQ_ROWS, (long long)c, n_groups);
     GQ_REQUIRE((group_size > 0 && (int64_t)group_size * n_groups >= c) || (group_size == 0 && col_group),
                "gq_dequantize: need a uniform group_size covering all columns, or group_size 0 with col_group");
-    const size_t lds = (size_t)((c + 15) & ~15);
+    const size_t lds = (size_t)DQ_ROWS * (((c + 15) & ~15) + (size_t)n_groups * 3) + 16;   // rows of levels, their scales and zero points
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GQ_F16) {
         GQ_HIP(hipFuncSetAttribute((const void *)dequant_kernel<GQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(dequant_kernel<GQ_F16>, dim3((unsigned)r), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
+        hipLaunchKernelGGL(dequant_kernel<GQ_F16>, dim3((unsigned)gq_cdiv(r, DQ_ROWS)), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, r, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
     } else {
         GQ_HIP(hipFuncSetAttribute((const void *)dequant_kernel<GQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(dequant_kernel<GQ_BF16>, dim3((unsigned)r), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
+        hipLaunchKernelGGL(dequant_kernel<GQ_BF16>, dim3((unsigned)gq_cdiv(r, DQ_ROWS)), dim3(256), lds, s, qweight, (const unsigned short *)scale, qzero, perm_inv, r, c, n_groups, group_size, col_group, (unsigned short *)weight_out);
     }
     GQ_LAUNCH_CHECK();
     return GQ_OK;
