@@ -59,6 +59,8 @@
 // tokens x 4096 features x 4096 deep 0.110 against 0.098 ms, x 11008 deep 0.264 against 0.224 ms.  Half of the
 // CUs at the clock the power budget then allows do as much as all of them at the lower one, and one wave per
 // SIMD has every wait of its own exposed.
+// The 4096 x 4096 launch (1146 TFLOP/s against 1350 on the wider shapes): starting every other workgroup 5-80 us
+// late so that the tiles' epilogues do not leave in one burst only added the delay (1112 ... 1076).
 // Cycle stamps per phase of a k-step (one wave of each SIMD pair, 12288 x 4096): the two waves of a SIMD do
 // not alternate.  After the barrier the older wave (0-3) wins the matrix pipe whenever it is ready, runs
 // its next three quarters nearly alone and then waits ~780 of the step's ~2300 cycles at the barrier,
