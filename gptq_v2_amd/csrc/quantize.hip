@@ -524,17 +524,34 @@ __global__ __launch_bounds__(256) void metrics_flat_kernel(const unsigned short 
     __shared__ double red[256];
     double se = 0.0, sn = 0.0, sw = 0.0;
     if (error_t) {
-        const int64_t total = r_total * c_total, n_threads = (int64_t)gridDim.x * gridDim.y * 256;
-        for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < total; i += n_threads) {
-            const float e = error_t[i];
-            se += (double)e * (double)e;
+        // 16 bytes per thread and turn, four turns in flight
+        // (a pointer that is not 16-byte aligned is walked element by element in the tail loop below)
+        const int64_t total4 = (((uintptr_t)error_t & 15) == 0) ? r_total * c_total / 4 : 0, n_threads = (int64_t)gridDim.x * gridDim.y * 256;
+        const f32x4 *e4 = reinterpret_cast<const f32x4 *>(error_t);
+        int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        for (; i + 3 * n_threads < total4; i += 4 * n_threads) {
+            f32x4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = e4[i + t * n_threads];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) se += (double)v[t][k] * (double)v[t][k];
         }
+        for (; i < total4; i += n_threads) {
+            const f32x4 v = e4[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) se += (double)v[k] * (double)v[k];
+        }
+        // (r * c is a multiple of 4 whenever the column loop ran: its row counts are; the odd tail otherwise)
+        for (int64_t t = total4 * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; t < r_total * c_total; t += n_threads)
+            se += (double)error_t[t] * (double)error_t[t];
     }
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < c_total) {
         const float ujj = u ? u[j * c_total + j] : 1.0f;
-        for (int64_t r = blockIdx.y; r < r_total; r += gridDim.y) {
-            const float wv = to_f32<DTYPE>(w[r * c_total + j]);
+        auto take = [&](unsigned short raw) {
+            const float wv = to_f32<DTYPE>(raw);
             // the reference squares in the weight's own 16-bit type (gptq_py.py:237): round each square
             float sq;
             if constexpr (DTYPE == GQ_F16) sq = (float)(_Float16)(wv * wv);
@@ -544,7 +561,19 @@ __global__ __launch_bounds__(256) void metrics_flat_kernel(const unsigned short 
                 const float q = wv / ujj;
                 sn += (double)q * (double)q;
             }
+        };
+        // eight rows per turn with their loads in flight together (one load per turn was a memory round trip
+        // per element and thread)
+        const int64_t step = gridDim.y;
+        int64_t r = blockIdx.y;
+        for (; r + 7 * step < r_total; r += 8 * step) {
+            unsigned short raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = w[(r + e * step) * c_total + j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) take(raw[e]);
         }
+        for (; r < r_total; r += step) take(w[r * c_total + j]);
     }
     block_add(se, sums + 0, red);
     block_add(sn, sums + 1, red);
