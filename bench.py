@@ -99,6 +99,7 @@ class Phase:
 
     def __init__(self):
         self.pairs = []
+        self.units = 0   # launches inside the phase's windows, where one window holds several
 
     def __enter__(self):
         import torch
@@ -148,10 +149,14 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
     for (c, outs), weights in zip(sets, ws):
         note(rank, "set C=%d" % c)
         x = xs[c]
-        hook = amd.HessianHook()
-        for bi in range(0, x.shape[0], batch):
-            with phases["xtx_%d" % c]:
+        hook = amd.HessianHook(overlap_batches=not os.environ.get("GQ_NO_OVERLAP"))   # the bench's inputs stay as they are
+        # one window per set: consecutive calls alternate between two accumulators on two streams and overlap at
+        # their ends; reading `hessian` joins the streams and sums the accumulators (part of the accumulation)
+        with phases["xtx_%d" % c] as ph:
+            for bi in range(0, x.shape[0], batch):
                 hook.add_batch(x[bi:bi + batch])
+                ph.units += 1
+            hook.hessian
         if world > 1:
             with phases["allreduce"]:
                 hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
@@ -430,7 +435,7 @@ def main():
 
         hidden = model["hidden"]
         px = phases["xtx_%d" % hidden]
-        t_call = px.total_ms() / max(px.count(), 1) * 1e-3
+        t_call = px.total_ms() / max(px.units, 1) * 1e-3   # per add_batch call, the final sum of the accumulators included
         tokens_call = min(args.batch, se - sb) * SEQ
         xtx_tflops = 2.0 * tokens_call * hidden * hidden / t_call / 1e12 if t_call > 0 else 0.0   # full product, as the algorithmic figure counts it
         # dominant kernel: the replay GEMM; algorithmic flops 2 M R C per launch and launch duration,

@@ -262,17 +262,18 @@ def quantize_llama(
         block.to(device)
         nxt = torch.empty_like(inps)
         if _is_llama_layout(block, sets) if staged is None else staged:
-            # stage 1: q, k, v see the first norm's output
-            hook = HessianHook()
+            # stage 1: q, k, v see the first norm's output.  (The hooks alternate between two accumulators where a
+            # call is a short launch; nothing below writes an input again before its set is quantised.)
+            hook = HessianHook(overlap_batches=True)
             run_until(block, sets[0][0], hook)
             quantise_set(gi, block, sets[0], hook)
             # stage 2: attention once; its output is o_proj's input
-            hook = HessianHook()
+            hook = HessianHook(overlap_batches=True)
             attn = torch.empty(n, inps.shape[1], _submodule(block, sets[1][0]).in_features, dtype=dtype, device=device)
             run_until(block, sets[1][0], hook, keep=attn)
             quantise_set(gi, block, sets[1], hook)
             # stage 3: h = x + o_proj(attn), z = norm2(h) feeds gate and up
-            hook = HessianHook()
+            hook = HessianHook(overlap_batches=True)
             o_proj = _submodule(block, sets[1][0])
             h, z = torch.empty_like(inps), torch.empty_like(inps)
             for b, e in batches:
@@ -282,7 +283,7 @@ def quantize_llama(
             del attn
             quantise_set(gi, block, sets[2], hook)
             # stage 4: a = act(gate(z)) * up(z) feeds down
-            hook = HessianHook()
+            hook = HessianHook(overlap_batches=True)
             gate, up = _submodule(block, sets[2][0]), _submodule(block, sets[2][1])
             act = torch.empty(n, inps.shape[1], gate.out_features, dtype=dtype, device=device)
             for b, e in batches:
@@ -296,7 +297,7 @@ def quantize_llama(
             del h, act, hook
         else:
             for names in sets:
-                hook = HessianHook()
+                hook = HessianHook(overlap_batches=True)
                 run_until(block, names[0], hook)
                 quantise_set(gi, block, names, hook)
                 del hook

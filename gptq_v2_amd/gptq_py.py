@@ -23,13 +23,25 @@ class HessianHook:
     """Running Hessian H = sum X^T X of one Linear's inputs and its inverse factor
     (gptq_py.py:9-66)."""
 
-    def __init__(self) -> None:
+    def __init__(self, overlap_batches: bool = False) -> None:
+        """``overlap_batches``: consecutive ``add_batch`` calls alternate between two accumulators on two side
+        streams, so that the first workgroups of one call fill the CUs that the last, partly empty round of
+        the previous call leaves idle (its launch is 408 workgroups of one per CU at C = 4096 and 946 at
+        C = 11008, on 256 CUs).  The caller's stream does not wait: an input must stay unmodified until
+        ``hessian`` is read (freeing it is fine).  ``hessian`` is the sum of all accumulators in a fixed
+        order, so it does not depend on timing.  Off by default: the reference's ``add_batch`` is ordered
+        with the caller's stream."""
         self._hessian: Optional[torch.Tensor] = None
         # With few output tiles (C = 4096) the tokens of a batch are cut into runs that accumulate into
         # partial Hessians (ops.xtx_accumulate_split); `_hessian` is then parts[0] and reading `hessian`
         # first adds the other parts into it.
         self._parts: Optional[torch.Tensor] = None
         self._parts_dirty = False
+        self._overlap = bool(overlap_batches)
+        self._lanes = 1          # accumulators that take turns (2 with overlap_batches where it pays)
+        self._per_lane = 1       # partial Hessians of one accumulator (the token split)
+        self._calls = 0
+        self._lane_streams: list = []
         self.n_samples: int = 0
         self.hessian_inv: Optional[torch.Tensor] = None
         self.perm: Optional[torch.Tensor] = None
@@ -40,6 +52,9 @@ class HessianHook:
     @property
     def hessian(self) -> Optional[torch.Tensor]:
         if self._parts_dirty:
+            main = torch.cuda.current_stream(self._parts.device)
+            for st in self._lane_streams:
+                main.wait_stream(st)
             ops.xtx_fold(self._parts)
             self._parts_dirty = False
         return self._hessian
@@ -49,6 +64,7 @@ class HessianHook:
         self._hessian = value
         self._parts = None
         self._parts_dirty = False
+        self._lanes = self._per_lane = 1
 
     @torch.no_grad()
     def add_batch(self, inp: torch.Tensor, use_kernel: bool = True) -> None:
@@ -67,8 +83,19 @@ class HessianHook:
         x = inp.flatten(end_dim=-2)
         if self._hessian is None:
             n_parts = ops.xtx_split_hint(d, x.shape[0]) if use_kernel and inp.is_cuda else 1
-            if n_parts > 1:
-                self._parts = torch.zeros(n_parts, d, d, dtype=torch.float32, device=inp.device)
+            lanes = 1
+            if self._overlap and use_kernel and inp.is_cuda and d % 256 == 0 and x.shape[0] >= 8192:
+                # worth a second accumulator when a call is at most two rounds of workgroups and the last one is at
+                # most 90 % full (C = 4096: 1.6 rounds).  With more rounds the idle share is small and two calls
+                # working on different tokens at once cost more in the XCDs' L2s than the tail gives back
+                # (C = 11008, 3.7 rounds: 28.1 -> 30.9 ms per block with two accumulators).
+                nt = d // 256
+                rounds = nt * (nt + 1) // 2 * n_parts / 256.0
+                if rounds <= 2.0 and -(-rounds // 1) - rounds >= 0.1:
+                    lanes = 2
+            self._lanes, self._per_lane = lanes, n_parts
+            if lanes * n_parts > 1:
+                self._parts = torch.zeros(lanes * n_parts, d, d, dtype=torch.float32, device=inp.device)
                 self._hessian = self._parts[0]
             else:
                 self._hessian = torch.zeros(d, d, dtype=torch.float32, device=inp.device)
@@ -77,7 +104,22 @@ class HessianHook:
             return
         if not x.is_contiguous():
             x = x.contiguous()
-        if self._parts is not None:
+        if self._lanes > 1:
+            lane = self._calls % self._lanes
+            self._calls += 1
+            if not self._lane_streams:
+                self._lane_streams = _side_streams(inp.device)[:self._lanes]
+            st = self._lane_streams[lane]
+            st.wait_stream(torch.cuda.current_stream(inp.device))   # x was produced there
+            x.record_stream(st)
+            mine = self._parts[lane * self._per_lane:(lane + 1) * self._per_lane]
+            with torch.cuda.stream(st):
+                if self._per_lane > 1:
+                    ops.xtx_accumulate_split(mine, x, save_lower_only=False, compute_lower_only=True)
+                else:
+                    ops.xtx_accumulate(mine[0], x, save_lower_only=False, compute_lower_only=True)
+            self._parts_dirty = True
+        elif self._parts is not None:
             ops.xtx_accumulate_split(self._parts, x, save_lower_only=False, compute_lower_only=True)
             self._parts_dirty = True
         else:

@@ -77,3 +77,40 @@ def test_hook_splits_at_4096_and_matches_unsplit(amd, gpu):
     hook3.add_batch(x)
     hook3.hessian = torch.ones(1, device=gpu)
     assert hook3._parts is None and hook3.hessian.numel() == 1
+
+
+def test_hook_with_two_accumulators_matches_one(amd, gpu):
+    """overlap_batches: calls alternate between two accumulators on two streams where a call is a short
+    launch (C = 4096), and nowhere else.  The sum is taken in a fixed order: the same calls give the same
+    bits, equal to the one-accumulator Hessian up to the order of the fp32 sums; an input may be freed
+    right after the call; the caller's stream sees the finished sum when it reads `hessian`."""
+    c = 4096
+    scale = 1 + 3 * torch.arange(c, device=gpu) / c
+
+    def run(overlap, seed=5):
+        gen = torch.Generator(device=gpu).manual_seed(seed)
+        hook = amd.HessianHook(overlap_batches=overlap)
+        for _ in range(5):    # an odd count: the accumulators get three and two calls
+            x = (torch.randn(8, 2048, c, generator=gen, device=gpu) * scale).half()
+            hook.add_batch(x)
+            del x             # freed while the side stream may still read it
+        return hook
+
+    two, one = run(True), run(False)
+    assert two._lanes == 2 and two._parts.shape == (6, c, c) and one._lanes == 1
+    h2, h1 = two.hessian.clone(), one.hessian
+    assert torch.equal(h2, h2.t())
+    assert float(two._parts[1:].abs().max()) == 0.0
+    assert float((h2 - h1).abs().max()) <= 1e-5 * float(h1.abs().max())
+    assert two.n_samples == one.n_samples == 40
+    assert torch.equal(run(True).hessian, h2)
+    u2, u1 = two.invert(), one.invert()
+    assert torch.equal(two.perm, one.perm)
+    assert float((u2 - u1).abs().max()) <= 1e-3 * float(u1.abs().max())
+    # long launches (C = 11008 fills the chip several times) and short inputs keep one accumulator
+    wide = amd.HessianHook(overlap_batches=True)
+    wide.add_batch(torch.zeros(8, 2048, 11008, dtype=torch.float16, device=gpu))
+    assert wide._lanes == 1
+    short = amd.HessianHook(overlap_batches=True)
+    short.add_batch(torch.zeros(2048, c, dtype=torch.float16, device=gpu))
+    assert short._lanes == 1
