@@ -474,7 +474,9 @@ def main():
                              "bound": "mfma", "achieved": round(xtx_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(xtx_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                              "traffic": pmc_bytes(os.path.join(ROOT, "profiles", "xtx_traffic.json")),
-                             "avg_launch_ms": round(t_call * 1e3, 4)},
+                             "avg_launch_ms": round(t_call * 1e3, 4),
+                             "timing": "window of a set's add_batch calls and the final sum, divided by the calls "
+                                       "(consecutive calls overlap on two streams), not one launch alone"},
         }
         if world > 1:
             h_bytes = sum(4.0 * c * c for c, _ in sets)
