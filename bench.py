@@ -125,6 +125,11 @@ def make_inputs(torch, dev, sets, n_local, seed):
     for c in sorted({c for c, _ in sets}):
         x = torch.empty(n_local, SEQ, c, dtype=torch.float16, device=dev)
         colscale = 1.0 + 3.0 * torch.arange(c, device=dev) / c
+        # feature magnitudes in no particular order, as a model's are: the activation order is then a permutation
+        # without structure (with the scales ascending it is close to a reversal, which makes every gather by it
+        # a nearly contiguous read and flatters the kernels that apply it)
+        if not os.environ.get("GQ_BENCH_MONOTONE"):
+            colscale = colscale[torch.randperm(c, generator=gen, device=dev)]
         for i in range(0, n_local, 4):
             x[i:i + 4] = (torch.randn(x[i:i + 4].shape, generator=gen, device=dev) * colscale).half()
         xs[c] = x

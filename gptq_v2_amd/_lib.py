@@ -53,8 +53,8 @@ SIGNATURES = {
                                      ctypes.POINTER(ctypes.c_int32), c_int, c_int, ctypes.POINTER(GridOptions),
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
-    "gq_quant_metrics": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                 c_void_p]),
+    "gq_quant_metrics": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_void_p, c_void_p]),
     "gq_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p,
                               c_int, c_void_p, c_void_p]),
     "gq_pack_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),

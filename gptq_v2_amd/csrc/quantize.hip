@@ -455,20 +455,33 @@ __device__ __forceinline__ void load_w_tile(float (*tile)[65], const unsigned sh
     }
 }
 
+// wt[j][r] = W[r][perm[j]] as fp32.  A tile is 64 rows x 64 columns of W as they lie in memory; column s of W
+// goes to row perm_inv[s] of wt, 256 contiguous bytes per tile and column.  (Picking the columns perm[j] of a
+// row instead reads a 64-byte sector for every 2-byte weight unless the order is nearly monotone: 11008 x 4096
+// took 0.75-1.0 ms so, against 0.11 ms.)
 template <int DTYPE>
-__global__ __launch_bounds__(256) void prep_kernel(const unsigned short *__restrict__ w, const int32_t *__restrict__ perm,
+__global__ __launch_bounds__(256) void prep_kernel(const unsigned short *__restrict__ w, const int32_t *__restrict__ perm_inv,
                                                    int64_t r_total, int64_t c_total, float *__restrict__ wt)
 {
     __shared__ float tile[64][65];
     const int64_t r0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
-    load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
+    load_w_tile<DTYPE>(tile, w, nullptr, r_total, c_total, r0, j0);
     __syncthreads();
     const int rr = threadIdx.x & 63;
 #pragma unroll 4
     for (int pass = 0; pass < 16; ++pass) {
         const int jj = (threadIdx.x >> 6) + 4 * pass;
-        if (j0 + jj < c_total && r0 + rr < r_total) wt[(j0 + jj) * r_total + r0 + rr] = tile[jj][rr];
+        if (j0 + jj < c_total && r0 + rr < r_total) {
+            const int64_t dst = perm_inv ? perm_inv[j0 + jj] : j0 + jj;
+            wt[dst * r_total + r0 + rr] = tile[jj][rr];
+        }
     }
+}
+
+__global__ void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t c, int32_t *__restrict__ perm_inv)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < c) perm_inv[perm[j]] = (int32_t)j;
 }
 
 // ---- metrics ----------------------------------------------------------------------------------
@@ -486,10 +499,13 @@ __device__ __forceinline__ void block_add(double v, double *dst, double *red)
 
 // sums[2] += (quant_t[j][r] - W[r][perm[j]])^2 over 64x64 tiles: blockIdx.x = row tile, the column
 // tiles are strided over blockIdx.y (a few hundred workgroups in all: each ends in one double
-// atomic on the same address, and thousands of those serialise)
+// atomic on the same address, and thousands of those serialise).  With perm_inv the tiles are columns of W
+// as they lie in memory and column s is compared with row perm_inv[s] of quant_t (contiguous reads on both
+// sides); without it the columns perm[j] are picked from W.
 template <int DTYPE>
 __global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short *__restrict__ w,
-                                                           const int32_t *__restrict__ perm, int64_t r_total,
+                                                           const int32_t *__restrict__ perm,
+                                                           const int32_t *__restrict__ perm_inv, int64_t r_total,
                                                            int64_t c_total, const float *__restrict__ quant_t,
                                                            double *__restrict__ sums)
 {
@@ -500,12 +516,13 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short 
     double acc = 0.0;
     for (int64_t j0 = (int64_t)blockIdx.y * 64; j0 < c_total; j0 += (int64_t)gridDim.y * 64) {
         __syncthreads();
-        load_w_tile<DTYPE>(tile, w, perm, r_total, c_total, r0, j0);
+        load_w_tile<DTYPE>(tile, w, perm_inv ? nullptr : perm, r_total, c_total, r0, j0);
         __syncthreads();
         for (int pass = 0; pass < 16; ++pass) {
             const int jj = (threadIdx.x >> 6) + 4 * pass;
             if (j0 + jj < c_total && r0 + rr < r_total) {
-                const float d = quant_t[(j0 + jj) * r_total + r0 + rr] - tile[jj][rr];
+                const int64_t row = perm_inv ? perm_inv[j0 + jj] : j0 + jj;
+                const float d = quant_t[row * r_total + r0 + rr] - tile[jj][rr];
                 acc += (double)d * (double)d;
             }
         }
@@ -668,11 +685,17 @@ int check_groups(const int32_t *sizes, const int32_t *bits, int n_groups, int64_
     return GQ_OK;
 }
 
+// `inv_scratch`: C ints, free until the kernel has run
 template <int DTYPE>
-int launch_prep(const void *weight, const int32_t *perm, int64_t r, int64_t c, float *wt, hipStream_t stream)
+int launch_prep(const void *weight, const int32_t *perm, int32_t *inv_scratch, int64_t r, int64_t c, float *wt, hipStream_t stream)
 {
+    if (perm) {
+        hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)gq_cdiv(c, 256)), dim3(256), 0, stream, perm, c, inv_scratch);
+        GQ_LAUNCH_CHECK();
+    }
     dim3 grid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
-    hipLaunchKernelGGL(prep_kernel<DTYPE>, grid, dim3(256), 0, stream, (const unsigned short *)weight, perm, r, c, wt);
+    hipLaunchKernelGGL(prep_kernel<DTYPE>, grid, dim3(256), 0, stream, (const unsigned short *)weight,
+                       perm ? (const int32_t *)inv_scratch : nullptr, r, c, wt);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }
@@ -1030,8 +1053,9 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
     std::vector<int64_t> gstart(n_groups + 1, 0);
     for (int g = 0; g < n_groups; ++g) gstart[g + 1] = gstart[g] + gs[g];
 
-    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, r, c, ws.wt, stream)
-                         : launch_prep<GQ_BF16>(weight, perm, r, c, ws.wt, stream);
+    // (the inverse permutation borrows the C floats of the scale steps, which are written much later)
+    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, (int32_t *)ws.sscale_g, r, c, ws.wt, stream)
+                         : launch_prep<GQ_BF16>(weight, perm, (int32_t *)ws.sscale_g, r, c, ws.wt, stream);
     if (rc) return rc;
 
     // Grids of groups [g0, g1) from the working weights as they are now (quant.py:89-118).  With the
@@ -1230,9 +1254,9 @@ extern "C" int gq_quantize_layer_ex(const void *weight, int dtype, const int32_t
                                error_t, workspace, workspace_bytes, (hipStream_t)stream_, "gq_quantize_layer_ex");
 }
 
-extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
-                                const float *quant_t, const float *error_t, int64_t r, int64_t c, double *sums,
-                                gq_stream_t stream_)
+extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const int32_t *perm_inv,
+                                const float *hessian_inv, const float *quant_t, const float *error_t, int64_t r,
+                                int64_t c, double *sums, gq_stream_t stream_)
 {
     GQ_REQUIRE(weight && quant_t && sums, "gq_quant_metrics: NULL pointer");
     GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_quant_metrics: bad dtype %d", dtype);
@@ -1245,10 +1269,10 @@ extern "C" int gq_quant_metrics(const void *weight, int dtype, const int32_t *pe
     dim3 fg((unsigned)cb, (unsigned)std::max<int64_t>(1, std::min<int64_t>(r, 512 / cb)));
     const unsigned short *w = (const unsigned short *)weight;
     if (dtype == GQ_F16) {
-        hipLaunchKernelGGL(metrics_tile_kernel<GQ_F16>, tgrid, dim3(256), 0, stream, w, perm, r, c, quant_t, sums);
+        hipLaunchKernelGGL(metrics_tile_kernel<GQ_F16>, tgrid, dim3(256), 0, stream, w, perm, perm ? perm_inv : nullptr, r, c, quant_t, sums);
         hipLaunchKernelGGL(metrics_flat_kernel<GQ_F16>, dim3(fg), dim3(256), 0, stream, w, hessian_inv, error_t, r, c, sums);
     } else {
-        hipLaunchKernelGGL(metrics_tile_kernel<GQ_BF16>, tgrid, dim3(256), 0, stream, w, perm, r, c, quant_t, sums);
+        hipLaunchKernelGGL(metrics_tile_kernel<GQ_BF16>, tgrid, dim3(256), 0, stream, w, perm, perm ? perm_inv : nullptr, r, c, quant_t, sums);
         hipLaunchKernelGGL(metrics_flat_kernel<GQ_BF16>, dim3(fg), dim3(256), 0, stream, w, hessian_inv, error_t, r, c, sums);
     }
     GQ_LAUNCH_CHECK();

@@ -262,12 +262,14 @@ def gptq_quant_set(
     if not weights:
         return []
     device = weights[0].device
-    perm32 = None
+    perm32 = perm_inv32 = None
     u = None
     if hessian_hook is not None:
         u = hessian_hook.hessian_inv
         if hessian_hook.perm is not None:
             perm32 = hessian_hook.perm.to(torch.int32).contiguous()
+            if hessian_hook.perm_inv is not None:
+                perm_inv32 = hessian_hook.perm_inv.to(torch.int32).contiguous()
         # gptq_py.py:95-96 zeroes columns whose Hessian diagonal is 0; after invert() no diagonal
         # entry is 0 any more (dead ones were set to 1, then damped), so nothing is zeroed there either.
     sem = ops.SEM_KERNEL if gptq_use_kernel else ops.SEM_PYTHON
@@ -303,7 +305,7 @@ def gptq_quant_set(
                     # whatever the caller enqueues next (reconstruction, the replay).  They read the weight and U:
                     # both are kept alive below until the sums have been fetched, and must not be overwritten
                     # before (wait=True, or settle()).
-                    sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"])
+                    sums = ops.quant_metrics(w[b:e], perm32, u, res["quant_t"], res["error_t"], perm_inv32)
                     sums_ready = torch.cuda.Event()
                     sums_ready.record(st)
                 main.wait_event(levels_ready)   # (waiting for the sums here instead: 5.22 against 5.19 s for the 7B job)

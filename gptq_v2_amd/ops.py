@@ -284,14 +284,19 @@ def quantize_layer(weight: torch.Tensor, perm: Optional[torch.Tensor], hessian_i
             "quant_t": quant_t, "error_t": error_t}
 
 
-def quant_metrics(weight, perm, hessian_inv, quant_t, error_t) -> torch.Tensor:
-    """Returns the four sums (double, device) behind gptq_quant's metrics."""
+def quant_metrics(weight, perm, hessian_inv, quant_t, error_t, perm_inv=None) -> torch.Tensor:
+    """Returns the four sums (double, device) behind gptq_quant's metrics.  ``perm_inv`` (int32, the inverse
+    of ``perm``) is optional and only makes the call faster."""
     _check(weight, "weight", None, 2)
     r, c = weight.shape
+    if perm_inv is not None:
+        _check(perm_inv, "perm_inv", torch.int32, 1)
+        if perm is None or perm_inv.numel() != c:
+            raise ValueError("quant_metrics: perm_inv needs perm and one entry per column")
     sums = torch.empty(4, dtype=torch.float64, device=weight.device)
     with torch.cuda.device(weight.device):
-        rc = _lib.load().gq_quant_metrics(_p(weight), _dtype_code(weight), _p(perm), _p(hessian_inv), _p(quant_t),
-                                          _p(error_t), r, c, _p(sums), _stream(weight))
+        rc = _lib.load().gq_quant_metrics(_p(weight), _dtype_code(weight), _p(perm), _p(perm_inv), _p(hessian_inv),
+                                          _p(quant_t), _p(error_t), r, c, _p(sums), _stream(weight))
     _lib.check(rc, "gq_quant_metrics")
     return sums
 

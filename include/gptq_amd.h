@@ -223,11 +223,13 @@ int gq_quantize_rtn(const void *weight, int dtype, int64_t r, int64_t c,
  *   writes it), sums[2] = sum((quant[r][j] - W[r][perm[j]])^2), sums[3] = sum(W^2) with every
  *   square rounded to the weight's 16-bit type first, as the reference computes it.
  * `sums` (double[4], device) is zeroed by the call.  error_t / hessian_inv may be NULL (their
- * sums stay 0).  The caller divides by R*C.
+ * sums stay 0).  The caller divides by R*C.  perm_inv (int32[C], the inverse of perm as
+ * gq_hessian_invert returns it) is optional: with it W is read as it lies in memory and quant_t row by
+ * row, which is several times faster for an order that is not nearly monotone.
  * ref: gptq_py.py:195-200, 231-238. */
-int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const float *hessian_inv,
-                     const float *quant_t, const float *error_t, int64_t r, int64_t c, double *sums,
-                     gq_stream_t stream);
+int gq_quant_metrics(const void *weight, int dtype, const int32_t *perm, const int32_t *perm_inv,
+                     const float *hessian_inv, const float *quant_t, const float *error_t, int64_t r,
+                     int64_t c, double *sums, gq_stream_t stream);
 
 /* weight_out[R][C] (fp16/bf16) = ((int16)q - (int16)z) * scale per group, evaluated in the output
  * dtype, then columns un-permuted: out[:, j] = deq[:, perm_inv[j]] (perm_inv int32[C] or NULL).

@@ -170,3 +170,48 @@ def test_reconstruct_nn_linear_places_result_like_the_reference(amd, gpu):
     on_gpu = amd.reconstruct_nn_linear(meta, dtype=torch.float16, device=gpu)
     assert on_cpu.weight.device.type == "cpu" and on_gpu.weight.device.type == "cuda"
     assert torch.equal(on_cpu.weight.data, on_gpu.weight.data.cpu())
+
+
+@pytest.mark.parametrize("c", [1024, 1100, 1027])
+def test_invert_applies_an_unstructured_order_exactly(amd, gpu, c):
+    """The permuted, scaled Hessian that invert() leaves behind is H[perm][:, perm] * 2 / n + damp on the
+    diagonal, bit for bit, for an activation order without structure (hidden sizes with and without 16-byte
+    rows: the row-staged gather has a path for each)."""
+    gen = torch.Generator(device=gpu).manual_seed(c)
+    x = torch.randn(2 * c, c, generator=gen, device=gpu) * (0.5 + torch.rand(c, generator=gen, device=gpu))
+    h = (x.t() @ x).contiguous()
+    h = (h + h.t()) / 2
+    hook = amd.HessianHook()
+    hook.hessian, hook.n_samples = h.clone(), 4
+    hook.invert(damp_ratio=1e-2, act_order=True)
+    perm = hook.perm
+    assert torch.equal(torch.sort(perm).values, torch.arange(c, device=gpu))
+    assert int((perm[1:] - perm[:-1]).abs().max()) > c // 4          # no structure
+    scaled = h * 0.5
+    want = scaled[perm][:, perm].clone()
+    assert torch.equal(want.diagonal(), torch.sort(scaled.diagonal(), descending=True).values)
+    got = hook.hessian.clone()
+    damp = got.diagonal() - want.diagonal()
+    assert float(damp.min()) > 0 and float(damp.max() - damp.min()) <= 1e-6 * float(want.diagonal().max())
+    got.diagonal().copy_(want.diagonal())
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_metric_sums_with_and_without_the_inverse_order(amd, gpu, dtype):
+    """gq_quant_metrics reads W through perm or, given perm_inv, quant_t through perm_inv: the same sums
+    (double accumulation; only the order of the additions differs)."""
+    r, c = 200, 1100
+    gen = torch.Generator(device=gpu).manual_seed(9)
+    w = (torch.randn(r, c, generator=gen, device=gpu) * 0.05).to(dtype)
+    perm = torch.randperm(c, generator=gen, device=gpu).to(torch.int32)
+    perm_inv = torch.empty_like(perm)
+    perm_inv[perm.long()] = torch.arange(c, device=gpu, dtype=torch.int32)
+    quant_t = (w.float()[:, perm.long()] + 0.01 * torch.randn(r, c, generator=gen, device=gpu)).t().contiguous()
+    a = amd.ops.quant_metrics(w, perm, None, quant_t, None)
+    b = amd.ops.quant_metrics(w, perm, None, quant_t, None, perm_inv)
+    exact = float(((quant_t.t().double() - w.double()[:, perm.long()]) ** 2).sum())
+    assert abs(float(a[2]) - exact) <= 1e-12 * exact and abs(float(b[2]) - exact) <= 1e-12 * exact
+    assert torch.equal(a[3], b[3]) or abs(float(a[3] - b[3])) <= 1e-12 * float(a[3])
+    with pytest.raises(ValueError):
+        amd.ops.quant_metrics(w, None, None, quant_t, None, perm_inv)
