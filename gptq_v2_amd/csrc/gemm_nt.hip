@@ -61,6 +61,10 @@
 // SIMD has every wait of its own exposed.
 // The 4096 x 4096 launch (1146 TFLOP/s against 1350 on the wider shapes): starting every other workgroup 5-80 us
 // late so that the tiles' epilogues do not leave in one burst only added the delay (1112 ... 1076).
+// Rotating the w panels from band to band, so that the XCDs (which work on different bands) never read the same w
+// panel at the same time (with bands of 4 all eight start a 4096 x 4096 launch on panels 0-7): 1075-1078 against
+// 1068-1082 TFLOP/s there, nothing on 12288 x 4096, 11008 x 4096 and 4096 x 11008, +1 % on 22016 x 4096 (which
+// two launches of 11008 rows beat by 6 % anyway): the shared panels are not what holds the short launch back.
 // Cycle stamps per phase of a k-step (one wave of each SIMD pair, 12288 x 4096): the two waves of a SIMD do
 // not alternate.  After the barrier the older wave (0-3) wins the matrix pipe whenever it is ready, runs
 // its next three quarters nearly alone and then waits ~780 of the step's ~2300 cycles at the barrier,
