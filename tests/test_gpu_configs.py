@@ -22,7 +22,8 @@ def test_opt125m_linear_shapes(amd, oracle, gpu, r, c):
     level, scale and zero of the native-loop semantics identical to the oracle's, and the
     PyTorch-loop semantics within the tolerance of its fp32 summation order."""
     gen = torch.Generator().manual_seed(r * 7 + c)
-    xs = [(torch.randn(8, 2048, c, generator=gen) * (1 + 3 * torch.arange(c) / c)).half() for _ in range(4)]
+    scales = (1 + 3 * torch.arange(c) / c)[torch.randperm(c, generator=gen)]   # no structure in the activation order
+    xs = [(torch.randn(8, 2048, c, generator=gen) * scales).half() for _ in range(4)]
     w = (torch.randn(r, c, generator=gen) * 0.02).half()
     hook, oh = amd.HessianHook(), oracle.OracleHessian()
     for x in xs:
@@ -58,8 +59,9 @@ def test_llama70b_down_proj_sizes(amd, gpu):
     c, r, n = 28672, 256, 4096
     gen = torch.Generator(device=gpu).manual_seed(11)
     hook = amd.HessianHook()
+    scales = (1 + 3 * torch.arange(c, device=gpu) / c)[torch.randperm(c, generator=gen, device=gpu)]
     for _ in range(2):
-        x = (torch.randn(1, n // 2, c, generator=gen, device=gpu) * (1 + 3 * torch.arange(c, device=gpu) / c)).half()
+        x = (torch.randn(1, n // 2, c, generator=gen, device=gpu) * scales).half()
         hook.add_batch(x)
     del x
     diag_before = hook.hessian.diagonal().clone()
@@ -107,7 +109,8 @@ def test_llama13b_shapes_with_sample_shards(amd, gpu):
     for c, r in ((5120, 1280), (13824, 640)):
         gen = torch.Generator(device=gpu).manual_seed(c)
         n_seq, seq = 16, 512
-        x = (torch.randn(n_seq, seq, c, generator=gen, device=gpu) * (1 + 3 * torch.arange(c, device=gpu) / c)).half()
+        scales = (1 + 3 * torch.arange(c, device=gpu) / c)[torch.randperm(c, generator=gen, device=gpu)]
+        x = (torch.randn(n_seq, seq, c, generator=gen, device=gpu) * scales).half()
         whole = amd.HessianHook()
         whole.add_batch(x)
         total = torch.zeros(c, c, device=gpu)

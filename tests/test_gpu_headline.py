@@ -13,9 +13,16 @@ pytestmark = pytest.mark.gpu
 C = 11008
 
 
+def _feature_scales(c, device):
+    """1 .. 4 in an order without structure (the same for every call): the activation order is then a
+    permutation without structure too, as a model's is"""
+    order = torch.randperm(c, generator=torch.Generator().manual_seed(c)).to(device)
+    return (1 + 3 * torch.arange(c, device=device) / c)[order]
+
+
 def _activations(gpu, n_seq, seq, seed):
     gen = torch.Generator(device=gpu).manual_seed(seed)
-    return (torch.randn(n_seq, seq, C, generator=gen, device=gpu) * (1 + 3 * torch.arange(C, device=gpu) / C)).half()
+    return (torch.randn(n_seq, seq, C, generator=gen, device=gpu) * _feature_scales(C, gpu)).half()
 
 
 @pytest.fixture(scope="module")
