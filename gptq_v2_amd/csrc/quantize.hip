@@ -1053,9 +1053,12 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
     std::vector<int64_t> gstart(n_groups + 1, 0);
     for (int g = 0; g < n_groups; ++g) gstart[g + 1] = gstart[g] + gs[g];
 
-    // (the inverse permutation borrows the C floats of the scale steps, which are written much later)
-    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, (int32_t *)ws.sscale_g, r, c, ws.wt, stream)
-                         : launch_prep<GQ_BF16>(weight, perm, (int32_t *)ws.sscale_g, r, c, ws.wt, stream);
+    // (the inverse permutation, 4 C bytes, borrows the start of the zero-point grids -- R C bytes with R >= 4 whenever
+    // there is a permutation -- which are first written after this kernel, on the same stream)
+    static_assert(sizeof(int32_t) == 4, "");
+    GQ_REQUIRE(!perm || r >= 4, "%s: a column permutation needs at least 4 rows", who);
+    rc = dtype == GQ_F16 ? launch_prep<GQ_F16>(weight, perm, (int32_t *)ws.zero_g, r, c, ws.wt, stream)
+                         : launch_prep<GQ_BF16>(weight, perm, (int32_t *)ws.zero_g, r, c, ws.wt, stream);
     if (rc) return rc;
 
     // Grids of groups [g0, g1) from the working weights as they are now (quant.py:89-118).  With the

@@ -215,3 +215,40 @@ def test_metric_sums_with_and_without_the_inverse_order(amd, gpu, dtype):
     assert torch.equal(a[3], b[3]) or abs(float(a[3] - b[3])) <= 1e-12 * float(a[3])
     with pytest.raises(ValueError):
         amd.ops.quant_metrics(w, None, None, quant_t, None, perm_inv)
+
+
+@pytest.mark.parametrize("r,c", [(8, 1024), (4, 2048), (64, 384)])
+def test_quantize_layer_stays_inside_its_workspace(amd, gpu, r, c):
+    """gq_quantize_layer with a column permutation, its workspace cut out of the middle of a buffer filled with a
+    pattern: the bytes on both sides are untouched (few rows make every region of the workspace small next to
+    the per-column scratch), and the levels equal those of a call with a workspace of its own."""
+    from gptq_v2_amd import _lib
+    from gptq_v2_amd import ops
+    lib = _lib.load()
+    gen = torch.Generator(device=gpu).manual_seed(r * c)
+    w = (torch.randn(r, c, generator=gen, device=gpu) * 0.05).half()
+    x = torch.randn(2 * c, c, generator=gen, device=gpu)
+    hook = amd.HessianHook()
+    hook.hessian, hook.n_samples = (x.t() @ x).contiguous(), 2
+    u = hook.invert()
+    perm = hook.perm.to(torch.int32).contiguous()
+    gs = [128] * (c // 128)
+    want = ops.quantize_layer(w, perm, u, gs, [4] * len(gs))
+    need = lib.gq_quantize_layer_workspace(r, c)
+    guard = 1 << 16
+    buf = torch.full((guard + need + guard,), 0xA5, dtype=torch.uint8, device=gpu)
+    qweight = torch.empty(r, c, dtype=torch.uint8, device=gpu)
+    scale = torch.empty(r, len(gs), dtype=torch.float16, device=gpu)
+    qzero = torch.empty(r, len(gs), dtype=torch.uint8, device=gpu)
+    quant_t = torch.empty(c, r, device=gpu)
+    error_t = torch.empty(c, r, device=gpu)
+    arr = ops._int_array
+    with torch.cuda.device(gpu):
+        rc = lib.gq_quantize_layer(w.data_ptr(), ops._dtype_code(w), perm.data_ptr(), u.data_ptr(), r, c, arr(gs),
+                                   arr([4] * len(gs)), len(gs), 0, ops.SEM_KERNEL, qweight.data_ptr(), scale.data_ptr(),
+                                   qzero.data_ptr(), quant_t.data_ptr(), error_t.data_ptr(), buf.data_ptr() + guard, need,
+                                   ops._stream(w))
+    _lib.check(rc, "gq_quantize_layer")
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + need:] == 0xA5).all())
+    assert torch.equal(qweight, want["qweight"]) and torch.equal(scale, want["scale"]) and torch.equal(qzero, want["qzero"])
