@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     }
 }
 
-// h[i][i] += damp, and the index-reversed, identity-padded work matrix  w[i][j] = h[c-1-i][c-1-j]
-__global__ void damp_flip_kernel(float *__restrict__ h, int64_t c, int64_t cp, const float *__restrict__ damp,
-                                 float *__restrict__ w)
+// h[i][i] += damp, and the index-reversed, identity-padded work matrix  w[i][j] = h[c-1-i][c-1-j].
+// With `src` the matrix is read from there and h is written whole: the first try after the act-order gather takes
+// the gathered matrix from the workspace and leaves it in `hessian` on the way (a copy of its own before this
+// kernel was one more read of C^2 floats).
+__global__ void damp_flip_kernel(float *__restrict__ h, const float *__restrict__ src, int64_t c, int64_t cp,
+                                 const float *__restrict__ damp, float *__restrict__ w)
 {
     const float d = *damp;
     const int64_t total = cp * cp;
@@ -189,11 +192,9 @@ __global__ void damp_flip_kernel(float *__restrict__ h, int64_t c, int64_t cp, c
         float v;
         if (r < c && col < c) {
             const int64_t sr = c - 1 - r, sc = c - 1 - col;
-            v = h[sr * c + sc];
-            if (sr == sc) {
-                v += d;
-                h[sr * c + sc] = v;
-            }
+            v = src ? src[sr * c + sc] : h[sr * c + sc];
+            if (sr == sc) v += d;
+            if (src || sr == sc) h[sr * c + sc] = v;
         } else {
             v = r == col ? 1.0f : 0.0f;
         }
@@ -803,9 +804,11 @@ int invert_setup(InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_
 }
 
 // scale by 2 / n, dead-diagonal fix, damping value, act-order permutation of H: everything before the tries
+// (`*gathered`: where the first try finds the matrix when it is not in `hessian` yet, else NULL)
 int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int32_t *perm_inv, int64_t c, double n_samples,
-                   float damp_ratio, int act_order, hipStream_t stream, const char *who)
+                   float damp_ratio, int act_order, hipStream_t stream, const char *who, const float **gathered)
 {
+    *gathered = nullptr;
     GQ_REQUIRE(n_samples > 0, "%s: n_samples must be positive", who);
     GQ_REQUIRE(!act_order || (perm && perm_inv), "%s: act_order needs perm and perm_inv buffers", who);
     const int64_t cc = c * c;
@@ -835,7 +838,7 @@ int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int
             hipLaunchKernelGGL(gather_kernel, dim3(ew_blocks(cc)), dim3(256), 0, stream, hessian, perm, c, scale, ws.t);
         }
         GQ_LAUNCH_CHECK();
-        GQ_HIP(hipMemcpyAsync(hessian, ws.t, (size_t)cc * 4, hipMemcpyDeviceToDevice, stream));
+        *gathered = ws.t;
     }
     return GQ_OK;
 }
@@ -843,12 +846,12 @@ int invert_prepare(const InvertWorkspace &ws, float *hessian, int32_t *perm, int
 // One try, enqueued: damp the diagonal once more (in place, as the reference's loop does), factor and
 // invert a copy; the factor is flipped into hessian_inv on the device when the try succeeded
 // (flip_out_kernel looks at the status word itself).
-int invert_try(const InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_t c, hipStream_t stream)
+int invert_try(const InvertWorkspace &ws, float *hessian, const float *gathered, float *hessian_inv, int64_t c, hipStream_t stream)
 {
     const int64_t cp = gq_round_up(c, NB);
     GQ_HIP(hipFuncSetAttribute((const void *)leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
     GQ_HIP(hipMemsetAsync(ws.status, 0, 256, stream));
-    hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, c, cp, ws.damp, ws.w);
+    hipLaunchKernelGGL(damp_flip_kernel, dim3(ew_blocks(cp * cp)), dim3(256), 0, stream, hessian, gathered, c, cp, ws.damp, ws.w);
     GQ_LAUNCH_CHECK();
     static const bool recursive = [] {   // experiments: GQ_INVERT=rec selects the recursive form
         const char *e = getenv("GQ_INVERT");
@@ -869,7 +872,7 @@ int invert_try(const InvertWorkspace &ws, float *hessian, float *hessian_inv, in
 // The tries after `tries` already made, one host round trip each, starting from the verdict of the last one
 // (verdict[0]: a pivot was not positive, verdict[1]: the diagonal of H is not finite).
 int invert_retry(const InvertWorkspace &ws, float *hessian, float *hessian_inv, int64_t c, int max_try, int tries,
-                 int verdict[2], int *tries_host, hipStream_t stream, const char *who)
+                 int verdict[2], int *tries_host, hipStream_t stream, const char *who, const float *gathered = nullptr)
 {
     for (;;) {
         if (verdict[1]) {
@@ -883,8 +886,9 @@ int invert_retry(const InvertWorkspace &ws, float *hessian, float *hessian_inv, 
         }
         if (tries >= max_try) break;
         ++tries;
-        const int rc = invert_try(ws, hessian, hessian_inv, c, stream);
+        const int rc = invert_try(ws, hessian, gathered, hessian_inv, c, stream);
         if (rc) return rc;
+        gathered = nullptr;   // `hessian` holds the matrix from the first try on
         GQ_HIP(hipMemcpyAsync(&verdict[0], ws.status, sizeof(int), hipMemcpyDeviceToHost, stream));
         GQ_HIP(hipMemcpyAsync(&verdict[1], ws.fatal, sizeof(int), hipMemcpyDeviceToHost, stream));
         GQ_HIP(hipStreamSynchronize(stream));
@@ -902,10 +906,11 @@ int invert_impl(float *hessian, float *hessian_inv, int32_t *perm, int32_t *perm
     InvertWorkspace ws;
     int rc = invert_setup(ws, hessian, hessian_inv, c, workspace, workspace_bytes, who);
     if (rc) return rc;
-    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who);
+    const float *gathered = nullptr;
+    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who, &gathered);
     if (rc) return rc;
     int verdict[2] = {1, 0};   // "not yet factored": the first pass of the loop makes try 1
-    return invert_retry(ws, hessian, hessian_inv, c, max_try, 0, verdict, tries_host, stream, who);
+    return invert_retry(ws, hessian, hessian_inv, c, max_try, 0, verdict, tries_host, stream, who, gathered);
 }
 
 }  // namespace
@@ -935,9 +940,10 @@ extern "C" int gq_hessian_invert_begin(float *hessian, float *hessian_inv, int32
     InvertWorkspace ws;
     int rc = invert_setup(ws, hessian, hessian_inv, c, workspace, workspace_bytes, who);
     if (rc) return rc;
-    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who);
+    const float *gathered = nullptr;
+    rc = invert_prepare(ws, hessian, perm, perm_inv, c, n_samples, damp_ratio, act_order, stream, who, &gathered);
     if (rc) return rc;
-    rc = invert_try(ws, hessian, hessian_inv, c, stream);
+    rc = invert_try(ws, hessian, gathered, hessian_inv, c, stream);
     if (rc) return rc;
     GQ_HIP(hipMemcpyAsync(verdict_dev, ws.status, sizeof(int), hipMemcpyDeviceToDevice, stream));
     GQ_HIP(hipMemcpyAsync(verdict_dev + 1, ws.fatal, sizeof(int), hipMemcpyDeviceToDevice, stream));
