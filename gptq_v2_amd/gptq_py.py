@@ -89,6 +89,11 @@ class HessianHook:
                 # most 90 % full (C = 4096: 1.6 rounds).  With more rounds the idle share is small and two calls
                 # working on different tokens at once cost more in the XCDs' L2s than the tail gives back
                 # (C = 11008, 3.7 rounds: 28.1 -> 30.9 ms per block with two accumulators).
+                # (For those longer calls the other way to fill the last round was built and measured too: ONE accumulator,
+                # every call as two launches on two streams -- workgroups 0..767 and 768..945 at C = 11008 -- so that the
+                # full rounds of call k+1, ordered behind those of call k, may run beside the rest of call k, which
+                # touches other tiles.  Bit-identical H, 27.3 -> 27.07 ms per block where filling the round would give
+                # 25.3: the second queue's launch is not placed while the first still has workgroups waiting.)
                 nt = d // 256
                 rounds = nt * (nt + 1) // 2 * n_parts / 256.0
                 if rounds <= 2.0 and -(-rounds // 1) - rounds >= 0.1:
