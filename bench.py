@@ -13,7 +13,9 @@ One step = the hot path of ONE decoder block, in the order the reference's drive
     replay of all batches through the reconstructed Linears of the set (llama.py:176-177: dense
     x W^T on the reconstructed weight, on this library's own MFMA kernel)
 The reported value is the wall-clock of the whole model: ms_per_step * blocks (all blocks have the
-same shapes).  Inputs are resident in HBM before the timed region.
+same shapes).  Inputs are resident in HBM before the timed region.  The activations' feature scales (1 .. 4)
+are drawn in random order, so the activation order is a permutation without structure (GQ_BENCH_MONOTONE=1:
+scales ascending with the column index, the draw of earlier lines in profiles/).
 
 `serving` (rank 0, outside the timed region): QuantLinear.forward -- the packed int4 x fp16 GEMM --
 of the 7 Linears of a block at seq 2048 x batch 1 and 8.
