@@ -473,7 +473,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const unsigned short *__restr
         const int jj = (threadIdx.x >> 6) + 4 * pass;
         if (j0 + jj < c_total && r0 + rr < r_total) {
             const int64_t dst = perm_inv ? perm_inv[j0 + jj] : j0 + jj;
-            wt[dst * r_total + r0 + rr] = tile[jj][rr];
+            // (an index array that is not a permutation leaves entries of its inverse at -1: those columns are dropped)
+            if ((uint64_t)dst < (uint64_t)c_total) wt[dst * r_total + r0 + rr] = tile[jj][rr];
         }
     }
 }
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const unsigned short *__restr
 __global__ void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t c, int32_t *__restrict__ perm_inv)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < c) perm_inv[perm[j]] = (int32_t)j;
+    if (j < c && (uint32_t)perm[j] < (uint32_t)c) perm_inv[perm[j]] = (int32_t)j;
 }
 
 // ---- metrics ----------------------------------------------------------------------------------
@@ -522,8 +523,10 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const unsigned short 
             const int jj = (threadIdx.x >> 6) + 4 * pass;
             if (j0 + jj < c_total && r0 + rr < r_total) {
                 const int64_t row = perm_inv ? perm_inv[j0 + jj] : j0 + jj;
-                const float d = quant_t[row * r_total + r0 + rr] - tile[jj][rr];
-                acc += (double)d * (double)d;
+                if ((uint64_t)row < (uint64_t)c_total) {
+                    const float d = quant_t[row * r_total + r0 + rr] - tile[jj][rr];
+                    acc += (double)d * (double)d;
+                }
             }
         }
     }
@@ -690,6 +693,7 @@ template <int DTYPE>
 int launch_prep(const void *weight, const int32_t *perm, int32_t *inv_scratch, int64_t r, int64_t c, float *wt, hipStream_t stream)
 {
     if (perm) {
+        GQ_HIP(hipMemsetAsync(inv_scratch, 0xff, (size_t)c * sizeof(int32_t), stream));
         hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)gq_cdiv(c, 256)), dim3(256), 0, stream, perm, c, inv_scratch);
         GQ_LAUNCH_CHECK();
     }
