@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void xtx_mfma_kernel(float *__restrict__ hess,
     const int lane = tid & 63;
 
     // XCD-aware remap (bijective for any grid size): blocks with equal blockIdx % 8 share an XCD
-    // and get a contiguous range of the tile table, which lists the tiles super-tile by super-tile
-    // (see build_tile_table): the ~100 tiles an XCD has in flight then touch ~20 column panels of
+    // and get a contiguous range of the tile order, which lists the tiles super-tile by super-tile
+    // (see xtx_tile_of): the ~100 tiles an XCD has in flight then touch ~20 column panels of
     // X instead of all of them, and X streams from HBM once per super-tile instead of once per row.
     int bid;
     {
