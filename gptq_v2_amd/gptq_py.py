@@ -183,6 +183,10 @@ class HessianHook:
 # HIP gives a process 4 hardware queues by default and streams beyond that share a queue, where a
 # wait of one stream holds up the kernels of the other behind it: three side streams plus the
 # caller's stream stay within the four (no set of a Llama block has more than three Linears).
+# (Raising the limit instead -- GPU_MAX_HW_QUEUES=8 with four or six side streams and as many slices -- was
+# measured: the column loops of a Llama-2-7B block 17.4 -> 22-23 ms, and the inversions, which run on the
+# caller's stream alone, 19.9 -> 32 ms.  Dependent kernels of one stream start later when the process has
+# more hardware queues to poll.)
 # The graph is a plain fork / join -- every side stream waits for the caller's stream once, the
 # caller's stream waits once for the levels of every job (an event behind its column loop; the metric
 # sums behind that event are waited for by the host only), no side stream waits for another, no event is
