@@ -45,8 +45,13 @@ def test_opt125m_linear_shapes(amd, oracle, gpu, r, c):
         res = amd.gptq_quant(w.to(gpu), hook, gs, gb, gptq_use_kernel=False, gptq_block_sizes=gs, quant_mse=False)
         want = oracle.gptq_quant(w, oh, gs, gb, use_kernel_semantics=False, block_sizes=gs)
         q, qr = res["quant_meta"]["qweight"].int(), want["quant_meta"]["qweight"].int()
-        assert (q - qr).abs().max() <= 1 and (q != qr).float().mean() <= 5e-3
+        n_off = int((q != qr).sum())
+        print(f"PyTorch-loop semantics {r}x{c}: {n_off} of {q.numel()} levels differ from the oracle's")
+        assert (q - qr).abs().max() <= 1 and n_off <= PYSEM_LEVELS_OFF_768
         assert torch.equal(res["quant_meta"]["scale"][:, 0], want["quant_meta"]["scale"][:, 0])
+
+
+PYSEM_LEVELS_OFF_768 = 0   # the count measured on an MI355X (of 589 824 levels)
 
 
 def test_llama70b_down_proj_sizes(amd, gpu):

@@ -86,13 +86,17 @@ def test_static_grids_with_options_bit_exact(amd, oracle, gpu, name):
             assert (meta["qscale"].int() - t(g["qscale"]).int()).abs().max() <= 1
 
 
+# levels that may differ from the reference's: the count measured on an MI355X (none), as in test_gpu_parity.py
+PYSEM_LEVELS_OFF = {"f8_pysem_blocks128_g64_64x256": 0, "f8_pysem_blocks64_g128_64x256": 0}
+
+
 @pytest.mark.parametrize("name,exact_groups", [("f8_pysem_blocks128_g64_64x256", 2), ("f8_pysem_blocks64_g128_64x256", 1)])
 def test_python_semantics_blocks_differ_from_groups(amd, oracle, gpu, name, exact_groups):
     """The PyTorch loop with blocks of 128 over groups of 64 (a group that starts inside a block takes
     its grid from the weights as they were when the block began: the first TWO grids come from the
     unmodified weights and are exact) and with blocks of 64 over groups of 128.  Later columns
-    depend on the summation order of the reference's fp32 matmuls: at most 0.5 % of the levels may
-    differ, by one level."""
+    depend on the summation order of the reference's fp32 matmuls: a level may differ by one; how many
+    do is printed and held to the measured count."""
     g, res, _ = _run(amd, oracle, name, gpu)
     meta = res["quant_meta"]
     assert torch.equal(meta["scale"][:, :exact_groups], t(g["scale"])[:, :exact_groups])
@@ -100,7 +104,9 @@ def test_python_semantics_blocks_differ_from_groups(amd, oracle, gpu, name, exac
     q, qr = meta["qweight"].int(), t(g["qweight"]).int()
     assert torch.equal(q[:, 0], qr[:, 0])
     assert (q - qr).abs().max() <= 1
-    assert (q != qr).float().mean() <= 5e-3
+    n_off = int((q != qr).sum())
+    print(f"{name}: {n_off} of {q.numel()} levels differ from the reference's")
+    assert n_off <= PYSEM_LEVELS_OFF[name]
     s, sr = meta["scale"].float(), t(g["scale"]).float()
     assert ((s - sr).abs() <= 2 * 2 ** -10 * sr.abs()).all()
     got = np.array([res["metrics"][k] for k in ("gptq_error", "gptq_norm", "l2.0_error", "l2.0_norm")])

@@ -399,12 +399,19 @@ def test_gptq_quant_kernel_semantics_bit_exact(amd, gpu, case):
     assert torch.allclose(y.float(), t(g["lin_y"]).float(), rtol=2e-3, atol=2e-3)
 
 
+# Levels that may differ from the reference's PyTorch-loop output, given the reference's U.  Measured on an MI355X:
+# none, on every fixture -- the k-ascending fma chain of the update lands on the same side of every rounding
+# boundary as the reference's BLAS did.  Nothing guarantees that (the summation orders differ), so a change that
+# moves a handful of levels by one is to be looked at, not necessarily a bug; a broken update moves thousands.
+PYSEM_LEVELS_OFF = {"64x256_b4": 0, "128x384_b3": 0, "64x256_b4_noact": 0}
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_gptq_quant_python_semantics(amd, gpu, case):
     """PyTorch-loop semantics vs fixture F4 (pure reference).  The first group's grid and the very
     first column are independent of summation order: exact.  Later columns depend on fp32 matmul
-    summation order inside the reference's BLAS, which is not reproducible: at most 0.5 % of the
-    levels may differ, each by one level, scales within 2 fp16 ulp."""
+    summation order inside the reference's BLAS, which is not reproducible: a level may differ by one;
+    how many do is printed and held to the measured count (PYSEM_LEVELS_OFF), scales within 2 fp16 ulp."""
     g = load_golden(f"f4_pysem_{case}")
     res = _run_quant(amd, g, gpu, use_kernel=False)
     meta = res["quant_meta"]
@@ -413,7 +420,9 @@ def test_gptq_quant_python_semantics(amd, gpu, case):
     assert torch.equal(meta["qzero"][:, 0], t(g["qzero"])[:, 0])
     assert torch.equal(q[:, 0], qr[:, 0])
     assert (q - qr).abs().max() <= 1
-    assert (q != qr).float().mean() <= 5e-3
+    n_off = int((q != qr).sum())
+    print(f"f4_pysem_{case}: {n_off} of {q.numel()} levels differ from the reference's")
+    assert n_off <= PYSEM_LEVELS_OFF[case]
     s, sr = meta["scale"].float(), t(g["scale"]).float()
     assert ((s - sr).abs() <= 2 * 2 ** -10 * sr.abs()).all()
     assert (meta["qzero"].int() - t(g["qzero"]).int()).abs().max() <= 1
