@@ -18,7 +18,8 @@ class GridOptions(ctypes.Structure):
                 ("norm", c_float)]
 
 
-LIB_PATH = os.path.join(_HERE, "lib", "libgptq_amd.so")
+# GQ_LIB_PATH: another build of the same library (the instrumented copies tools/ makes); same symbols required
+LIB_PATH = os.environ.get("GQ_LIB_PATH") or os.path.join(_HERE, "lib", "libgptq_amd.so")
 
 # name -> (restype, argtypes); must list every function include/gptq_amd.h declares
 SIGNATURES = {
@@ -68,6 +69,7 @@ SIGNATURES = {
                            c_int, c_int, c_int, c_void_p]),
     "gq_wq_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "gq_set_wq_kernel": (c_int, [c_int]),
+    "gq_set_quant_super": (c_int, [c_int]),
     "gq_xtx_split_hint": (c_int, [c_int64, c_int64, c_int]),
     "gq_xtx_accumulate_split": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gq_xtx_fold": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p]),

@@ -13,6 +13,8 @@
 // The update of the columns behind the block is an fp32 MFMA GEMM (sgemm.hip) whose per-element
 // operation order (k ascending, fused multiply-add, starting from the old weight) is the same as
 // the in-block updates', so the result does not depend on how columns are cut into blocks.
+#include <stdlib.h>
+
 #include <type_traits>
 #include <vector>
 
@@ -379,6 +381,409 @@ extern "C" int gq_debug_qb_trace(unsigned long long *buf)
 }
 #endif
 
+// ---- a super-block of up to 512 columns in ONE launch (native-loop semantics, grids given) ------
+// The block kernel above is launched once per <= 128 columns and a GEMM launch between two of them
+// carries the errors into the next block: per 512 columns that is a chain of seven dependent launches
+// of 25-32 + 9 us each.  Here a workgroup owns 32 output features for a window of up to 512 columns,
+// held in LDS, and never returns to the host inside it:
+//   * wave 0 (the chain) walks 16 columns at a time, exactly as the block kernel walks a sub-block
+//     (same instructions per column, so the same bits);
+//   * the rank-16 update those 16 columns owe every later column of the window runs on the matrix
+//     core as 32-column tiles: the tile that holds the next two sub-blocks by wave 0 itself right
+//     before it walks on, everything behind it by waves 1-3 WHILE wave 0 walks the next sub-block;
+//   * one barrier per 16 columns.  Update j-1 reaches sub-block j+1 one phase before wave 0 applies
+//     update j to it, so every weight still receives its updates in ascending column order, each one
+//     fused multiply-add, starting from the old weight: the cut into tiles and phases changes no bit.
+// U is not staged: the chain's 16 x 16 piece goes through LDS (fetched one phase ahead by wave 3), the
+// tiles' operands come from memory straight into registers (every workgroup reads the same rows of
+// U at about the same time, so they are served by the XCD's L2).  Waves 1-3 also write the finished
+// sub-block's outputs (errors, dequantised values) with 16-byte stores; the levels leave as 16 bytes
+// per row and sub-block into a blocked layout [C/16][R][16] that unblock_q_kernel turns into [R][C].
+constexpr int SW = 512;       // columns of a window
+constexpr int SR = 32;        // output features per workgroup
+constexpr int SB = 16;        // columns per phase
+constexpr int SUS = 20;       // stride of a 16 x 16 piece of U in LDS (rows stay 16-byte aligned)
+constexpr int SW_PAD = 32;    // columns behind the window that the last tiles may touch (never stored)
+struct SuperTable {
+    float maxq[SW / SB];        // per sub-block: 2^bits - 1 of its group
+    uint16_t group[SW / SB];    // per sub-block: its group
+};
+constexpr int QS_LDS = ((SW + SW_PAD) * SR + 2 * SB * SR + 2 * SB * SUS + 2 * SB + 2 * 2 * SR) * 4 + 2 * SR * 16;
+
+#ifdef GQ_QS_TRACE
+// Debug build only (tools/trace_qs.py): cycle stamps of workgroup 0, [wave][phase < 12][5].
+__device__ unsigned long long *g_qs_trace = nullptr;
+#define QS_TR(k)                                                                                   \
+    do {                                                                                           \
+        if (g_qs_trace && blockIdx.x == 0 && lane == 0 && j < 12)                                  \
+            g_qs_trace[(wv * 12 + j) * 5 + (k)] = __builtin_readcyclecounter();                    \
+    } while (0)
+#else
+#define QS_TR(k)
+#endif
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and
+// store the wave has in flight; here loads are requested a phase ahead on purpose and the stores of outputs
+// need no ordering inside the kernel.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void quant_super_kernel(
+    const float *__restrict__ wt, float *__restrict__ quant_t, float *__restrict__ error_t, uint8_t *__restrict__ q_blk,
+    const float *__restrict__ u, int64_t ldu, const float *__restrict__ scale_g, const float *__restrict__ zero_g,
+    int64_t r_total, int a, int n, SuperTable tab)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *win = reinterpret_cast<float *>(smem_raw);   // [SW + SW_PAD][SR]  win[c][row]
+    float *ebuf = win + (SW + SW_PAD) * SR;             // [2][SB][SR]  -error of the last walked sub-block
+    float *usm = ebuf + 2 * SB * SR;                    // [2][SB][SUS] U[sj + i][sj + i2]
+    float *rdl = usm + 2 * SB * SUS;                    // [2][SB]      RN(1 / U[sj + i][sj + i])
+    float *szb = rdl + 2 * SB;                          // [2][2][SR]   scale, zero of the last two groups
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(szb + 4 * SR);   // [2][SR][4] levels, one byte each
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t r0 = (int64_t)blockIdx.x * SR;
+    const int64_t r = r0 + li;
+    const bool live = r < r_total;
+    const int64_t rr = live ? r : r_total - 1;          // dead lanes shadow the last row and store nothing
+    const int ns = n / SB;
+    const unsigned rt = (unsigned)r_total, lu = (unsigned)ldu;
+    const float *__restrict__ wbase = wt + (int64_t)a * r_total;
+    const float *__restrict__ ubase = u + (int64_t)a * ldu + a;   // U[a + i][a + c]
+    const int cmax = (int)(ldu - a) - 1;                // last column of U, counted from a
+
+    // U[sj + i][sj .. sj + 15] and the reciprocals of its diagonal for sub-block jn: one 16-byte load per lane
+    auto fetch_usm = [&](int jn) {
+        const int i = lane >> 2, c4 = (lane & 3) * 4, sjn = jn * SB;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ubase + ((unsigned)(sjn + i) * lu + (unsigned)(sjn + c4)));
+        *reinterpret_cast<f32x4 *>(usm + (jn & 1) * SB * SUS + i * SUS + c4) = v;
+        if ((i >> 2) == (lane & 3)) {
+            const int e = i & 3;
+            const float dg = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+            rdl[(jn & 1) * SB + i] = recip_rn(dg);
+        }
+    };
+
+    // ---- prologue: the window, the first piece of U, the first grid ------------------------------
+    float s_nx = 0.0f, z_nx = 0.0f;
+    {
+        const int sub = lane >> 3, q4 = (lane & 7) * 4;
+        int64_t r4 = r0 + q4;
+        if (r4 > r_total - 4) r4 = r_total - 4;         // (r_total is a multiple of 4)
+        f32x4 v[SW / 32];
+#pragma unroll
+        for (int i = 0; i < SW / 32; ++i) {
+            int c = wv * 8 + sub + 32 * i;
+            if (c > n - 1) c = n - 1;
+            v[i] = *reinterpret_cast<const f32x4 *>(wbase + ((unsigned)c * rt + (unsigned)r4));
+        }
+        if (wv == 0) {
+            const int g0 = tab.group[0];
+            s_nx = scale_g[(int64_t)g0 * r_total + rr];
+            z_nx = zero_g[(int64_t)g0 * r_total + rr];
+        }
+        if (wv == 3) fetch_usm(0);
+#pragma unroll
+        for (int i = 0; i < SW / 32; ++i) {
+            const int c = wv * 8 + sub + 32 * i;
+            if (c < n) *reinterpret_cast<f32x4 *>(win + c * SR + q4) = v[i];
+        }
+    }
+    __syncthreads();
+
+    if (wv == 0) {
+        // ---- the chain ---------------------------------------------------------------------------
+        // The tile of sub-blocks j and j+1 lives in the matrix core's accumulator layout: register e of lane
+        // (li, lh) is column 8 (e / 4) + e % 4 + 4 lh of the tile, row li.  Its second half stays in
+        // registers as the first half of the next phase's tile, so only the 16 columns that enter come from LDS.
+        float nerr[SB];           // minus the scaled errors of the sub-block walked last (both half-waves hold row li)
+        float a_la[SB / 2];       // U[rows of that sub-block][the 32 columns behind it], requested a phase ahead
+        float keep[8];            // second half of the last tile
+#pragma unroll
+        for (int i = 0; i < SB; ++i) nerr[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SB / 2; ++i) a_la[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep[i] = 0.0f;
+        float s = 1.0f, z = 0.0f, rs = 1.0f;
+        int g_cur = -1;
+        for (int j = 0; j <= ns; ++j) {
+            const int sj = j * SB;
+            QS_TR(0);
+            if (j < ns) {
+                // update j-1 for the tile that holds sub-blocks j and j+1
+                f32x16 acc;
+#pragma unroll
+                for (int e = 8; e < 16; ++e) acc[e] = win[(sj + 8 * (e >> 2) + (e & 3) + 4 * lh) * SR + li];
+                if (j == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = win[(8 * (e >> 2) + (e & 3) + 4 * lh) * SR + li];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = keep[e];
+#pragma unroll
+                    for (int k2 = 0; k2 < SB / 2; ++k2) {
+                        // (both values pinned to registers first: a select between two elements of an array becomes
+                        // an indexed load, which puts the whole array into scratch memory)
+                        float e0 = nerr[2 * k2], e1 = nerr[2 * k2 + 1];
+                        asm volatile("" : "+v"(e0), "+v"(e1));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_la[k2], lh ? e1 : e0, acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) keep[e] = acc[8 + e];
+                // the 16 columns to walk, all of them in every lane: the half-waves exchange their columns
+                float w0[SB];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[e]), __float_as_uint(acc[e]), false, false);
+                    w0[8 * (e >> 2) + (e & 3)] = __uint_as_float(pr[0]);
+                    w0[8 * (e >> 2) + (e & 3) + 4] = __uint_as_float(pr[1]);
+                }
+                QS_TR(1);
+                // operands of the next such update, and the next group's grid, on their way during the walk
+                if (j + 1 < ns) {
+                    int col = sj + SB + li;
+                    if (col > cmax) col = cmax;
+#pragma unroll
+                    for (int k2 = 0; k2 < SB / 2; ++k2) a_la[k2] = ubase[(unsigned)(sj + 2 * k2 + lh) * lu + (unsigned)col];
+                }
+                const int g = tab.group[j];
+                const float maxq = tab.maxq[j];
+                if (g != g_cur) {
+                    s = s_nx;
+                    z = z_nx;
+                    rs = recip_rn(s);
+                    g_cur = g;
+                    if (lh == 0) {
+                        szb[(g & 1) * 2 * SR + li] = s;
+                        szb[(g & 1) * 2 * SR + SR + li] = z;
+                    }
+                }
+                if (j + 1 < ns && tab.group[j + 1] != g) {
+                    const int g1 = tab.group[j + 1];
+                    s_nx = scale_g[(int64_t)g1 * r_total + rr];
+                    z_nx = zero_g[(int64_t)g1 * r_total + rr];
+                }
+                const float rdv = rdl[(j & 1) * SB + (lane & 15)];
+                const float *__restrict__ us = usm + (j & 1) * SB * SUS;
+                // fp16 dequantisation as one fused operation: (q - z) is exact in binary16 and so is z * hs in
+                // binary32, so RN16(q * hs - z * hs) is the reference's RN16((q - z) * hs); an hs that is not finite
+                // sends the sub-block down the plain path
+                const float hs32 = (float)(_Float16)s, nzhs = -((float)(_Float16)z * hs32);
+                const bool odd_grid = !(fabsf(hs32) <= 65504.0f);
+                float qv[SB];
+                auto walk = [&](auto fast_c) -> bool {
+                    constexpr bool FAST = decltype(fast_c)::value;
+                    DivRange bad;
+                    float w[SB];
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) w[i] = w0[i];
+                    // Row i+1 of the U piece comes out of LDS 16 bytes at a time (the same address in every lane) while
+                    // column i's updates run: the walk never holds more than two rows in registers.
+                    f32x4 ur[SB / 4], un[SB / 4];
+#pragma unroll
+                    for (int q = 0; q < SB / 4; ++q) ur[q] = *reinterpret_cast<const f32x4 *>(us + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        const float x = w[i];
+                        const float d = ur[i / 4][i % 4];
+                        const float rdi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rdv), i));
+                        float qf, diff;
+                        if constexpr (FAST) {
+                            const float quo = div_rn_fast(x, s, rs, bad);
+                            qf = __builtin_amdgcn_fmed3f(rintf(quo) + z, 0.0f, maxq);   // operands are finite here: a clamp
+                            float dq16;
+                            asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(dq16) : "v"(qf), "v"(hs32), "v"(nzhs));
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(diff) : "v"(dq16), "v"(x));
+                        } else {
+                            qf = clampf(rintf(x / s) + z, 0.0f, maxq);
+                            const _Float16 hx = (_Float16)qf, hz = (_Float16)z, hs = (_Float16)s;
+                            _Float16 hd = hx - hz;
+                            hd = hd * hs;
+                            diff = x - (float)hd;
+                        }
+                        float err;
+                        if constexpr (FAST) err = div_rn_fast(diff, d, rdi, bad);
+                        else err = diff / d;
+                        qv[i] = qf;
+                        nerr[i] = -err;
+                        // (the reads go out here, in front of the updates, which write no new register: issued in front
+                        // of the chain above, their destination registers were reused for its temporaries at once and
+                        // every column waited for LDS)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i + 1 < SB) {
+#pragma unroll
+                            for (int q = (i + 1) / 4; q < SB / 4; ++q) un[q] = *reinterpret_cast<const f32x4 *>(us + (i + 1) * SUS + 4 * q);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i2 = i + 1; i2 < SB; ++i2) w[i2] = fmaf(nerr[i], ur[i2 / 4][i2 % 4], w[i2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // (every component of what was read counts as used until here: the ones in front of the diagonal
+                        // are not needed, and a register that is dead while its load is in flight is handed to the next
+                        // temporary, whose write then waits for the load)
+#pragma unroll
+                        for (int q = (i + 1) / 4; q < SB / 4; ++q) asm volatile("" ::"v"(un[q]));
+#pragma unroll
+                        for (int q = (i + 1) / 4; q < SB / 4; ++q) ur[q] = un[q];
+                    }
+                    return bad.bad() || odd_grid;
+                };
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(walk(std::true_type{})) != 0, 0)) walk(std::false_type{});
+                QS_TR(2);
+                // what the other waves need of this sub-block: -errors (the half-waves write alternate columns),
+                // levels (one byte each)
+                u32x4 qp = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 0; i < SB; ++i) qp[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(qv[i], i & 3, qp[i >> 2]);
+                float *__restrict__ eb = ebuf + (j & 1) * SB * SR;
+#pragma unroll
+                for (int k2 = 0; k2 < SB / 2; ++k2) {
+                    float e0 = nerr[2 * k2], e1 = nerr[2 * k2 + 1];
+                    asm volatile("" : "+v"(e0), "+v"(e1));
+                    eb[(2 * k2 + lh) * SR + li] = lh ? e1 : e0;
+                }
+                if (lh == 0) {
+                    *reinterpret_cast<u32x4 *>(qbuf + ((j & 1) * SR + li) * 4) = qp;
+                    if (live) *reinterpret_cast<u32x4 *>(q_blk + ((int64_t)((a + sj) >> 4) * r_total + r) * 16) = qp;
+                }
+            } else {
+                QS_TR(1);
+                QS_TR(2);
+            }
+            QS_TR(3);
+            lds_barrier();
+            QS_TR(4);
+        }
+    } else {
+        // ---- waves 1-3: update j-1 for the tiles behind the one wave 0 has just taken, tile t on wave 1 + t % 3 ----
+        // A tile's piece of U comes from memory straight into registers, and memory is a microsecond away: the
+        // pieces of update j (applied next phase; U does not change) are requested before update j-1 is applied
+        // with the pieces requested a phase ago.
+        constexpr int ST = (SW / 32 + 2) / 3;   // tiles of one update a wave may own
+        float a_cur[ST][SB / 2], a_nxt[ST][SB / 2];
+#pragma unroll
+        for (int slot = 0; slot < ST; ++slot)
+#pragma unroll
+            for (int k2 = 0; k2 < SB / 2; ++k2) a_cur[slot][k2] = a_nxt[slot][k2] = 0.0f;
+        for (int j = 0; j <= ns; ++j) {
+            const int sj = j * SB;
+            QS_TR(0);
+            const int jp = j - 1, sp = jp * SB;
+            const float *__restrict__ eb = ebuf + (jp & 1) * SB * SR;
+            const int c_first = sj + 2 * SB;
+            const int nt = (j > 0 && n > c_first) ? (n - c_first + 31) >> 5 : 0;
+            const int c_next = sj + 3 * SB;
+            const int nt_next = (j < ns && n > c_next) ? (n - c_next + 31) >> 5 : 0;
+#pragma unroll
+            for (int slot = 0; slot < ST; ++slot) {
+                const int t = wv - 1 + 3 * slot;
+                if (t < nt_next) {
+                    int col = c_next + 32 * t + li;
+                    if (col > cmax) col = cmax;
+#pragma unroll
+                    for (int k2 = 0; k2 < SB / 2; ++k2) a_nxt[slot][k2] = ubase[(unsigned)(sj + 2 * k2 + lh) * lu + (unsigned)col];
+                }
+            }
+            QS_TR(1);
+            if (wv - 1 < nt) {
+                float b[SB / 2];
+#pragma unroll
+                for (int k2 = 0; k2 < SB / 2; ++k2) b[k2] = eb[(2 * k2 + lh) * SR + li];
+#pragma unroll
+                for (int slot = 0; slot < ST; ++slot) {
+                    const int t = wv - 1 + 3 * slot;
+                    if (t < nt) {
+                        const int c0 = c_first + 32 * t;
+                        f32x16 acc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] = win[(c0 + 8 * (e >> 2) + (e & 3) + 4 * lh) * SR + li];
+#pragma unroll
+                        for (int k2 = 0; k2 < SB / 2; ++k2)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[slot][k2], b[k2], acc, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) win[(c0 + 8 * (e >> 2) + (e & 3) + 4 * lh) * SR + li] = acc[e];
+                    }
+                }
+            }
+            QS_TR(2);
+            // outputs of sub-block j-1, by the wave with the fewest tiles: 16 bytes (4 rows of a column) per lane
+            if (j > 0 && wv == 1 + nt % 3) {
+                const int g = tab.group[jp];
+                const float *__restrict__ sz = szb + (g & 1) * 2 * SR;
+                const uint32_t *__restrict__ qb = qbuf + (jp & 1) * SR * 4;
+                const int i8 = lane >> 3, q4 = (lane & 7) * 4;
+                const bool ok = r0 + q4 < r_total;
+                const f32x4 sv = *reinterpret_cast<const f32x4 *>(sz + q4);
+                const f32x4 zv = *reinterpret_cast<const f32x4 *>(sz + SR + q4);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int i = pass * 8 + i8;
+                    const f32x4 ne = *reinterpret_cast<const f32x4 *>(eb + i * SR + q4);
+                    const int64_t o = (int64_t)(a + sp + i) * r_total + r0 + q4;
+                    if (ok) *reinterpret_cast<f32x4 *>(error_t + o) = f32x4{-ne[0], -ne[1], -ne[2], -ne[3]};
+                    if (quant_t) {
+                        f32x4 dq;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t word = qb[(q4 + e) * 4 + (i >> 2)];
+                            const float qf = (float)((word >> (8 * (i & 3))) & 0xffu);
+                            const _Float16 hx = (_Float16)qf, hz = (_Float16)zv[e], hs = (_Float16)sv[e];
+                            _Float16 hd = hx - hz;
+                            hd = hd * hs;
+                            dq[e] = (float)hd;
+                        }
+                        if (ok) *reinterpret_cast<f32x4 *>(quant_t + o) = dq;
+                    }
+                }
+            }
+            if (wv == 3 && j + 1 < ns) fetch_usm(j + 1);
+#pragma unroll
+            for (int slot = 0; slot < ST; ++slot)
+#pragma unroll
+                for (int k2 = 0; k2 < SB / 2; ++k2) a_cur[slot][k2] = a_nxt[slot][k2];
+            QS_TR(3);
+            lds_barrier();
+            QS_TR(4);
+        }
+    }
+}
+
+#ifdef GQ_QS_TRACE
+extern "C" int gq_debug_qs_trace(unsigned long long *buf)
+{
+    GQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qs_trace), &buf, sizeof(buf)));
+    return GQ_OK;
+}
+#endif
+
+// q_blk [C/16][R][16] (what quant_super_kernel writes) -> qweight [R][C]
+__global__ __launch_bounds__(256) void unblock_q_kernel(const uint8_t *__restrict__ src, int64_t r_total, int64_t c_total,
+                                                        uint8_t *__restrict__ dst)
+{
+    __shared__ u32x4 tile[64][17];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, cb0 = (int64_t)blockIdx.y * 16, n_cb = c_total / 16;
+    const int tr = threadIdx.x & 63, tq = threadIdx.x >> 6;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cb = tq + 4 * pass;
+        if (cb0 + cb < n_cb && r0 + tr < r_total)
+            tile[tr][cb] = *reinterpret_cast<const u32x4 *>(src + ((cb0 + cb) * r_total + r0 + tr) * 16);
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 15, rw = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = rw + 16 * pass;
+        if (cb0 + ch < n_cb && r0 + row < r_total)
+            *reinterpret_cast<u32x4 *>(dst + (r0 + row) * c_total + (cb0 + ch) * 16) = tile[row][ch];
+    }
+}
+
 // ---- one column, one thread per output feature ------------------------------------------------
 // The reference's own decomposition (gptq_cpp_kernel.cu:21-137: quantise column `col`, then the
 // rank-1 update of everything behind it), for the columns of a range that the blocked kernel cannot
@@ -735,6 +1140,43 @@ int launch_block(const QuantBlockArgs &p, int semantics, hipStream_t stream)
     return GQ_OK;
 }
 
+// 0: one launch per <= 128 columns (quant_block_kernel + a GEMM between two of them), 1: one launch per <= 512
+// columns (quant_super_kernel) where the layer allows it.  Same bits either way; the switch is for comparisons
+// and tests (gq_set_quant_super, or GQ_QUANT_SUPER=0 in the environment).
+int g_quant_super = -1;
+
+bool quant_super_enabled()
+{
+    if (g_quant_super < 0) {
+        const char *e = getenv("GQ_QUANT_SUPER");
+        g_quant_super = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_quant_super != 0;
+}
+
+// columns [s0, s1) of the layer (s1 - s0 <= 512, a multiple of 16), grids of all groups in scale_g / zero_g
+int launch_super(const float *wt, float *quant_t, float *error_t, uint8_t *q_blk, const float *u, int64_t c, int64_t r,
+                 const float *scale_g, const float *zero_g, const std::vector<int64_t> &gstart, const int32_t *gb,
+                 int64_t s0, int64_t s1, hipStream_t stream)
+{
+    SuperTable tab{};
+    size_t g = 0;
+    for (int64_t col = s0; col < s1; col += SB) {
+        while (gstart[g + 1] <= col) ++g;
+        tab.group[(col - s0) / SB] = (uint16_t)g;
+        tab.maxq[(col - s0) / SB] = (float)((1 << gb[g]) - 1);
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        GQ_HIP(hipFuncSetAttribute((const void *)quant_super_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QS_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(quant_super_kernel, dim3((unsigned)gq_cdiv(r, SR)), dim3(256), QS_LDS, stream, wt, quant_t, error_t,
+                       q_blk, u, c, scale_g, zero_g, r, (int)s0, (int)(s1 - s0), tab);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 // W^T[m0:m1] -= U[k0:k1, m0:m1]^T * E^T[k0:k1]   (k ascending, fused, starting from the old weight)
 int trailing_update(const float *u, float *wt, const float *error_t, int64_t c, int64_t r, int64_t k0, int64_t k1,
                     int64_t m0, int64_t m1, hipStream_t stream)
@@ -1008,6 +1450,13 @@ extern "C" int gq_quantize_range(float *quant, const float *scale, int16_t *out_
     return GQ_OK;
 }
 
+extern "C" int gq_set_quant_super(int on)
+{
+    const int before = quant_super_enabled() ? 1 : 0;
+    g_quant_super = on ? 1 : 0;
+    return before;
+}
+
 extern "C" size_t gq_quantize_layer_workspace(int64_t r, int64_t c)
 {
     if (r <= 0 || c <= 0) return 0;
@@ -1100,6 +1549,7 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
         return GQ_OK;
     };
     const bool plain_grid = !exl2 && !o.mse;
+    bool super = false;   // the column loop ran on quant_super_kernel
 
     if (!u) {   // round to nearest (gptq_py.py:101-124)
         const unsigned rg = (unsigned)gq_cdiv(r, 256);
@@ -1170,6 +1620,19 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
             }
         }
 
+        // Native-loop semantics with every group a multiple of 16 columns: one launch per 512 columns and one
+        // GEMM behind it (launch_super); anything else takes the block kernel below.
+        super = semantics == GQ_SEM_KERNEL && quant_super_enabled() && c % SB == 0 && n_groups <= 65535;
+        for (int g = 0; super && g < n_groups; ++g) super = gs[g] % SB == 0;
+        if (super) {
+            for (int64_t s0 = 0; s0 < c; s0 += SW) {
+                const int64_t s1 = std::min<int64_t>(c, s0 + SW);
+                if ((rc = launch_super(ws.wt, quant_t, err, ws.q_t, u, c, r, ws.scale_g, ws.zero_g, gstart, gb, s0, s1, stream))) return rc;
+                if ((rc = trailing_update(u, ws.wt, err, c, r, s0, s1, s1, c, stream))) return rc;
+            }
+            units.clear();
+        }
+
         // Units are gathered into super-blocks of about SUPER columns: after each launch only the
         // columns up to the super-block's eager end are updated (short GEMM, K = launch), the columns
         // behind it once per super-block (K = SUPER).  Each weight still receives its updates in
@@ -1205,8 +1668,13 @@ int quantize_layer_impl(const void *weight, int dtype, const int32_t *perm, cons
         }
     }
 
-    dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
-    hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
+    if (super) {   // the levels lie in 16-column pieces per row
+        dim3 ugrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 256));
+        hipLaunchKernelGGL(unblock_q_kernel, ugrid, dim3(256), 0, stream, ws.q_t, r, c, qweight);
+    } else {
+        dim3 tgrid((unsigned)gq_cdiv(r, 64), (unsigned)gq_cdiv(c, 64));
+        hipLaunchKernelGGL(transpose_u8_kernel, tgrid, dim3(256), 0, stream, ws.q_t, c, r, qweight);
+    }
     GQ_LAUNCH_CHECK();
     const unsigned cg = (unsigned)gq_cdiv(r * n_groups, 256);
     if (dtype == GQ_F16) {

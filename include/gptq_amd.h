@@ -310,6 +310,16 @@ int gq_wq_expand(void *w_out, const uint32_t *qweight_packed, const void *scale_
  * reference counterpart; the environment variable GQ_WQ_KERNEL=stream|split sets the initial value. */
 int gq_set_wq_kernel(int variant);
 
+/* How the column loop of gq_quantize_layer / gq_quantize_layer_ex is launched for native-loop semantics
+ * when every group is a multiple of 16 columns: 1 (the default) = one launch per 512 columns in which a
+ * workgroup keeps its 32 rows' window in LDS and updates it between 16-column steps on the matrix core,
+ * followed by one GEMM for the columns behind the window; 0 = one launch per 128 columns with a GEMM
+ * between every two.  Every weight receives the same fused multiply-adds in the same order either way, so
+ * all outputs are identical bit for bit; the switch exists for comparisons and tests.  Returns the
+ * previous setting.  A tuning knob of this library, no reference counterpart; the environment variable
+ * GQ_QUANT_SUPER=0 sets the initial value to 0. */
+int gq_set_quant_super(int on);
+
 /* y[M][N] = x[M][K] * w[N][K]^T for dense 16-bit operands (dtype GQ_F16 or GQ_BF16 for all three),
  * fp32 accumulation, one rounding of the result: the forward of the dense nn.Linear that the
  * reference builds from a reconstructed weight and runs over the calibration batches

@@ -159,10 +159,10 @@ def test_levels_and_metrics_of_the_walk(f10, walked):
         print(f"{name}: levels equal {same:.4f} (reference against itself at batch 4: {1 - f10['b4_level_mismatch'][i]:.4f}); "
               f"metrics rel diff {rel.round(4).tolist()}")
         if name in sets[0]:
-            assert same > 0.99, name
+            assert same > 0.98, name          # measured 0.991 .. 0.993: two adjacent columns of near-equal energy swapped
         # gptq_error, l2.0_error: the loss the loop minimises and the plain rounding error; *_norm do not depend on levels
-        assert rel[0] < 0.1 and rel[2] < 0.02 and rel[3] < 1e-5, name
-        assert rel[1] < 0.1, name
+        assert rel[0] < 0.05 and rel[2] < 0.02 and rel[3] < 1e-5, name   # measured: at most 0.013, 0.009, 0
+        assert rel[1] < 0.05, name                                        # measured: at most 0.011
 
 
 @pytest.mark.parametrize("batch_size", [1, 4])
