@@ -40,6 +40,9 @@ sys.path.insert(0, ROOT)
 SEQ = 2048
 # hidden, ffn, rows of k / v (grouped-query attention in 70B), decoder blocks
 MODELS = {
+    # OPT-125M (configuration 1 of the baseline: 32 calibration samples, the reference's pure-PyTorch CPU path):
+    # q/k/v/out 768 x 768, fc1 3072 x 768, fc2 768 x 3072; fc1 has a Hessian of its own (it reads the second norm)
+    "opt125m": dict(name="OPT-125M", hidden=768, ffn=3072, kv=768, blocks=12, opt=True, samples=32),
     "7b": dict(name="Llama-2-7B", hidden=4096, ffn=11008, kv=4096, blocks=32),
     "13b": dict(name="Llama-2-13B", hidden=5120, ffn=13824, kv=5120, blocks=40),
     "70b": dict(name="Llama-2-70B", hidden=8192, ffn=28672, kv=1024, blocks=80),
@@ -55,10 +58,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", choices=sorted(MODELS), default="7b")
     ap.add_argument("--bits", type=int, choices=(3, 4), default=4)
-    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--samples", type=int, default=None, help="calibration sequences (default 128; 32 for opt125m)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serving", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--replay", choices=("dense", "packed", "lib"), default="dense",
                     help="dense: x W^T on the reconstructed weight (what the reference runs); packed: the W4A16 GEMM; "
                          "lib: the dense replay through the library's GEMM, for comparison only")
@@ -70,6 +74,8 @@ def parse():
 def sets_of(model):
     h, f, kv = model["hidden"], model["ffn"], model["kv"]
     # (in_features, [out_features of the Linears sharing that input])
+    if model.get("opt"):
+        return [(h, [h, h, h]), (h, [h]), (h, [f]), (f, [h])]
     return [(h, [h, kv, kv]), (h, [h]), (h, [f, f]), (f, [h])]
 
 
@@ -286,20 +292,38 @@ def serving(torch, amd, sets, bits, dev):
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / reps
-        # the GEMMs alone (input already in act-order), for the matrix-pipe figure
+        # the GEMMs alone (input already in act-order), for the matrix-pipe figure, in both forms of the forward:
+        # "fused" = the packed kernels, levels expanded inside the GEMM (w4a16_kernel / w4a16_256_kernel /
+        # wq_stream_kernel); "expand_once" = the levels expanded once per call into a transient dense weight
+        # (gq_wq_expand, inside the timed call) and the dense kernel on it.  QuantLinear.forward picks by token count.
         xp = {c: xin[c] for c in xin}
-        s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s2.record()
-        for _ in range(reps):
-            for c, r, layer in layers:
-                layer.forward_permuted(xp[c])
-        e2.record()
-        torch.cuda.synchronize()
-        ms_gemm = s2.elapsed_time(e2) / reps
+
+        def gemm_only(min_tokens):
+            saved = amd.QuantLinear.expand_min_tokens
+            amd.QuantLinear.expand_min_tokens = min_tokens
+            try:
+                for c, r, layer in layers:
+                    layer.forward_permuted(xp[c])
+                s2, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s2.record()
+                for _ in range(reps):
+                    for c, r, layer in layers:
+                        layer.forward_permuted(xp[c])
+                e2.record()
+                torch.cuda.synchronize()
+                return s2.elapsed_time(e2) / reps
+            finally:
+                amd.QuantLinear.expand_min_tokens = saved
+
+        ms_gemm = gemm_only(amd.QuantLinear.expand_min_tokens)
+        ms_fused = gemm_only(0)
+        ms_expand = gemm_only(1)
         tf = flops / (ms_gemm * 1e-3) / 1e12
         out["seq2048_batch%d" % batch] = {"tokens": m, "block_forward_ms": round(ms, 4), "w4a16_gemm_ms": round(ms_gemm, 4),
                                           "w4a16_tflops": round(tf, 1),
-                                          "frac_of_f16_mfma_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+                                          "frac_of_f16_mfma_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                                          "fused_w4a16_tflops": round(flops / (ms_fused * 1e-3) / 1e12, 1),
+                                          "expand_once_tflops": round(flops / (ms_expand * 1e-3) / 1e12, 1)}
         # the Linears that read the same input as one layer each (QuantLinear.concat): q/k/v, gate/up
         if fused is not None:
             s3, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -316,6 +340,9 @@ def serving(torch, amd, sets, bits, dev):
                                                    "fused_qkv_gateup_tflops": round(flops / (ms_f * 1e-3) / 1e12, 1)})
         del xin, xp
     out["expand_once_from_tokens"] = amd.QuantLinear.expand_min_tokens
+    out["forward_picks"] = ("w4a16_tflops is QuantLinear.forward as shipped: the fused packed kernel below %d tokens per call "
+                            "(twice that for layers of fewer than 8192 rows), expand-once from there on; fused_w4a16_tflops and "
+                            "expand_once_tflops force one form for every layer" % amd.QuantLinear.expand_min_tokens)
     return out
 
 
@@ -366,6 +393,75 @@ def cpu_baseline(sets, n_blocks, n_seq, bits):
                       "gptq_py.py and are not in this figure" % (n_seq, n_blocks)}
 
 
+def cpu_baseline_whole(sets, n_blocks, n_seq, batch, bits, budget_s=25.0):
+    """Configuration 1 (OPT-125M): the reference's pure-PyTorch CPU path run as a whole, block after block in the
+    order llama.py runs a block -- per set add_batch over every calibration batch, invert, gptq_quant
+    (PyTorch-loop semantics) of each Linear -- through the oracle's restatement, not composed from separately
+    timed pieces.  Whole blocks are run until the time budget is used (at least one); all blocks have the same
+    shapes, so the model's figure is the per-block mean times the block count."""
+    import torch
+    from oracle import gptq_oracle as oracle
+    cores = torch.get_num_threads()
+    gen = torch.Generator().manual_seed(0)
+    xs = {c: (torch.randn(n_seq, SEQ, c, generator=gen) * (1 + 3 * torch.rand(c, generator=gen))).half()
+          for c in sorted({c for c, _ in sets})}
+    done, t_total = 0, 0.0
+    while done < n_blocks and (done == 0 or t_total + t_total / done <= budget_s):
+        ws = [[(torch.randn(r, c, generator=gen) * 0.02).half() for r in outs] for c, outs in sets]
+        t0 = time.perf_counter()
+        for (c, outs), weights in zip(sets, ws):
+            hook = oracle.OracleHessian()
+            for bi in range(0, n_seq, batch):
+                hook.add_batch(xs[c][bi:bi + batch])
+            hook.invert(1e-2, True)
+            gs = torch.full([c // 128], 128, dtype=torch.int32)
+            gb = torch.full([c // 128], bits, dtype=torch.int32)
+            for w in weights:
+                oracle.gptq_quant(w, hook, gs, gb, use_kernel_semantics=False, block_sizes=gs)
+        t_total += time.perf_counter() - t0
+        done += 1
+    return {"value": round(t_total / done * n_blocks, 1), "unit": "s", "cores": cores, "kind": "port",
+            "sample": "measured on this host: %d whole block(s) of the oracle's PyTorch-loop path (4 Hessians over %d sequences "
+                      "of 2048 tokens, 4 inversions, %d Linears each) in %.1f s; value = per-block mean x %d blocks"
+                      % (done, n_seq, sum(len(o) for _, o in sets), t_total, n_blocks)}
+
+
+def end_to_end(torch, dev, bits, n_seq, batch):
+    """The block walk itself -- gptq_v2_amd.driver.quantize_llama with attention, norms, rotary embedding, SwiGLU, hooks
+    and the copies of the results to the host -- on a random-initialised Llama with Llama-2-7B block dimensions
+    (no checkpoint is reachable offline), outside the timed region of the bench line.  Walks of 1 and of 3 blocks
+    are timed whole (host clock, device drained at both ends) after an untimed warm-up walk; their difference is two
+    blocks without the per-walk costs (embedding, capture of the first block's inputs)."""
+    try:
+        from transformers import LlamaConfig, LlamaForCausalLM
+    except Exception as exc:   # the walk needs the model classes only
+        return {"error": "transformers not importable: %r" % (exc,)}
+    from gptq_v2_amd import driver
+    enc = torch.randint(0, 32000, (n_seq, SEQ), generator=torch.Generator().manual_seed(11))
+    walls = {}
+    for n_blocks in (0, 1, 3):   # 0: an untimed one-block walk that takes the first-call costs (library handles, kernel loading)
+        cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=max(n_blocks, 1), num_attention_heads=32,
+                          num_key_value_heads=32, vocab_size=32000, max_position_embeddings=SEQ)
+        torch.manual_seed(0)
+        with torch.device(dev):
+            model = LlamaForCausalLM(cfg).half().eval()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        driver.quantize_llama(model, enc, dev, batch_size=batch, bits=bits, group_size=128)
+        torch.cuda.synchronize()
+        walls[n_blocks] = time.perf_counter() - t0
+        del model
+        torch.cuda.empty_cache()
+    per_block = (walls[3] - walls[1]) / 2.0
+    return {"what": "driver.quantize_llama on a random-init Llama with Llama-2-7B block dimensions, %d x %d tokens, batch %d: "
+                    "the real block walk (attention, norms, hooks, results copied to the host)" % (n_seq, SEQ, batch),
+            "wall_s_1_block": round(walls[1], 3), "wall_s_3_blocks": round(walls[3], 3),
+            "seconds_per_block": round(per_block, 4),
+            "value_32_blocks": round(32 * per_block, 2),
+            "value_32_blocks_is": "extrapolated: 32 x the marginal block of the 3-block walk; no 32-block model was run",
+            "reference_log": "123.45 s for the 32 blocks on an unnamed GPU (logs/log.txt:260), 3.78-3.97 s per block"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -399,6 +495,8 @@ def main():
     from gptq_v2_amd import dist as gd
 
     model = MODELS[args.model]
+    if args.samples is None:
+        args.samples = model.get("samples", 128)
     sets = sets_of(model)
     n_blocks = model["blocks"]
     sb, se = gd.sample_shard(args.samples, rank, world)
@@ -434,9 +532,14 @@ def main():
         steps = max(args.steps, 1)
         breakdown = {n: round(p.total_ms() / steps, 3) for n, p in phases.items() if p.count()}
 
-        def pmc_bytes(path):
+        def pmc_bytes(path, source):
+            """Memory-side bytes per launch from the committed rocprofv3 --pmc passes -- only while the kernel's source
+            is the one they were measured on (the file carries its SHA-256); a stale measurement reads as null."""
+            import hashlib
             try:
-                return json.load(open(path)).get("hbm_bytes_per_launch")
+                rec = json.load(open(path))
+                now = hashlib.sha256(open(os.path.join(ROOT, "gptq_v2_amd", "csrc", source), "rb").read()).hexdigest()
+                return rec.get("hbm_bytes_per_launch") if rec.get("source_sha256") == now else None
             except Exception:
                 return None
 
@@ -453,7 +556,8 @@ def main():
                          "lib": "the library's fp16 GEMM (torch.matmul; comparison run, not the product path",
                          "packed": "w4a16_256_kernel (y = x W4^T"}[args.replay]
         line = {
-            "metric": "llama2_%s_w%dg128_quantize_wallclock" % (args.model, args.bits),
+            "metric": ("opt125m_w%dg128_quantize_wallclock" % args.bits) if model.get("opt") else
+                      "llama2_%s_w%dg128_quantize_wallclock" % (args.model, args.bits),
             "value": round(ms_per_step * n_blocks / 1e3, 3),
             "unit": "s",
             "n_gpus": world,
@@ -468,19 +572,22 @@ def main():
             "config": {"workload": "%s %d-bit g=128 act-order, %d calib sequences x 2048 tokens, "
                                    "1 step = hot path of one decoder block (4 Hessians, 4 inversions, 7 Linears "
                                    "quantised, reconstructed, packed, and replayed as %s GEMMs); "
-                                   "value = %d blocks" % (model["name"], args.bits, args.samples, args.replay, n_blocks),
+                                   "value = %d blocks.  Against the reference's operation list (llama.py:141-179) the step "
+                                   "merges the replay of Linears that read one input into one launch per batch and leaves "
+                                   "out the copy of each quant_meta to the host (llama.py:173; the driver makes it on a "
+                                   "thread of its own, see end_to_end)" % (model["name"], args.bits, args.samples, args.replay, n_blocks),
                        "batch": args.batch, "parallelism": "dp%d samples + row-sharded quantize" % world},
             "breakdown_ms_per_step": breakdown,
             "roofline": {"kernel": "%s, %d tokens per launch, mean of the launches of a block)" % (replay_kernel, tokens_call),
                          "bound": "mfma", "achieved": round(replay_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(replay_tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_bytes(args.traffic_json),
+                         "traffic": pmc_bytes(args.traffic_json, "gemm_nt.hip") if args.replay == "dense" else None,
                          "avg_launch_ms": round(pr.total_ms() / max(pr.count(), 1), 4),
                          "avg_launch_flops": round(flops[0] / max(pr.count(), 1), 1), "launches": pr.count()},
             "roofline_xtx": {"kernel": "xtx256_kernel (H += X^T X, C=%d, %d tokens per launch)" % (hidden, tokens_call),
                              "bound": "mfma", "achieved": round(xtx_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(xtx_tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                             "traffic": pmc_bytes(os.path.join(ROOT, "profiles", "xtx_traffic.json")),
+                             "traffic": pmc_bytes(os.path.join(ROOT, "profiles", "xtx_traffic.json"), "xtx.hip"),
                              "avg_launch_ms": round(t_call * 1e3, 4),
                              "timing": "window of a set's add_batch calls and the final sum, divided by the calls "
                                        "(consecutive calls overlap on two streams), not one launch alone"},
@@ -498,8 +605,16 @@ def main():
             best = line["serving"]["seq2048_batch8"]
             line["int4_gemm_tflops"] = best["w4a16_tflops"]
             line["int4_gemm_frac_of_f16_mfma_peak"] = best["frac_of_f16_mfma_peak"]
+            line["int4_gemm_tflops_is"] = ("QuantLinear.forward at 16384 tokens = expand-once: packed weights at rest, expanded once per "
+                                           "call into a transient dense weight inside the timed call; the fused kernel's own figure is "
+                                           "serving.seq2048_batch8.fused_w4a16_tflops")
+        if world == 1 and not args.no_end_to_end and args.model == "7b":
+            line["end_to_end"] = end_to_end(torch, dev, args.bits, args.samples, args.batch)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sets, n_blocks, args.samples, args.bits)
+            if model.get("opt"):
+                line["cpu_baseline"] = cpu_baseline_whole(sets, n_blocks, args.samples, args.batch, args.bits)
+            else:
+                line["cpu_baseline"] = cpu_baseline(sets, n_blocks, args.samples, args.bits)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -172,10 +172,12 @@ class HessianHook:
 # update) that leaves most of the chip idle, so the Linears of a set run on separate HIP streams
 # and fill each other's gaps (measured on the Llama-2-7B block: 32.6 -> 27.4 ms).  Slicing the
 # rows of ONE Linear over streams does not pay: a slice's chain is barely shorter than the whole
-# layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1 -- except for a set
-# of ONE Linear (o_proj, down_proj), whose chain has nobody to share the chip with: its rows go to the three
-# side streams as three slices (SINGLE_SLICES), and one slice's update GEMM runs beside another's block kernel
-# (column loops of a Llama-2-7B block 20.2 -> 19.4 ms; the levels do not change, rows are independent).
+# layer's (1.95 vs 2.56 ms for a quarter of a 4096 x 4096 layer), so ROW_SLICES stays 1.  A set of ONE Linear
+# (o_proj, down_proj) has nobody to share the chip with; while the column loop was one launch per 128 columns,
+# cutting its rows into three slices on the three side streams paid (one slice's update GEMM beside another's
+# block kernel: 20.2 -> 19.4 ms per Llama-2-7B block).  With one launch per 512 columns the slices only get in
+# each other's way: o_proj 1.43 / 1.60 / 1.75 ms and down_proj 6.16 / 6.02 / 6.14 ms for 1 / 2 / 3 slices, so
+# SINGLE_SLICES is 1 (GQ_SINGLE_SLICES overrides it; the levels do not depend on it, rows are independent).
 # The opposite -- the rows of the set's Linears stacked into ONE column loop (bit for bit the same levels;
 # block launches of three times the workgroups, trailing updates of three times the tiles) -- was measured
 # too and is slower: 21.2 against 19.9 ms per Llama-2-7B block.  A stacked gate/up launch is 344 workgroups
@@ -193,7 +195,7 @@ class HessianHook:
 # recorded twice, no stream has a priority -- so it has no cycle whatever the queue mapping is.
 N_QUANT_STREAMS = 3
 ROW_SLICES = 1
-SINGLE_SLICES = int(os.environ.get("GQ_SINGLE_SLICES", "3"))
+SINGLE_SLICES = int(os.environ.get("GQ_SINGLE_SLICES", "1"))
 MIN_SLICE_ROWS = 256
 _streams: dict = {}
 
