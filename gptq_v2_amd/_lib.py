@@ -76,6 +76,8 @@ SIGNATURES = {
     "gq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 
+ABI_VERSION = 3   # GQ_ABI_VERSION of include/gptq_amd.h this table was written against
+
 _lib = None
 
 
@@ -95,6 +97,9 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.gq_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} implements interface version {lib.gq_version()}, this binding expects "
+                              f"{ABI_VERSION}: rebuild it (python gptq_v2_amd/build.py)")
         _lib = lib
     return _lib
 

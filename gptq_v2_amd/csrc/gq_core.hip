@@ -15,4 +15,4 @@ void gq_set_error(const char *fmt, ...)
 
 extern "C" const char *gq_last_error(void) { return g_last_error; }
 
-extern "C" int gq_version(void) { return 1; }
+extern "C" int gq_version(void) { return GQ_ABI_VERSION; }

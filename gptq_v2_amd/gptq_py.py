@@ -30,7 +30,8 @@ class HessianHook:
         C = 11008, on 256 CUs).  The caller's stream does not wait: an input must stay unmodified until
         ``hessian`` is read (freeing it is fine).  ``hessian`` is the sum of all accumulators in a fixed
         order, so it does not depend on timing.  Off by default: the reference's ``add_batch`` is ordered
-        with the caller's stream."""
+        with the caller's stream.  The FIRST call fixes the layout (how many accumulators, how the tokens
+        of a call are split) from its hidden size and token count; later calls of other lengths use it as it is."""
         self._hessian: Optional[torch.Tensor] = None
         # With few output tiles (C = 4096) the tokens of a batch are cut into runs that accumulate into
         # partial Hessians (ops.xtx_accumulate_split); `_hessian` is then parts[0] and reading `hessian`
@@ -48,6 +49,9 @@ class HessianHook:
         self.perm_inv: Optional[torch.Tensor] = None
         self.tries: int = 0
         self._pending = None   # ops.PendingInversion of invert(wait=False) until confirm() has looked at it
+        # counts rewrites of hessian_inv after it was handed out: work enqueued against an earlier generation is void
+        # (every gptq_quant_set remembers the generation it read U at and compares when it settles)
+        self._generation = 0
 
     @property
     def hessian(self) -> Optional[torch.Tensor]:
@@ -114,6 +118,10 @@ class HessianHook:
             self._calls += 1
             if not self._lane_streams:
                 self._lane_streams = _side_streams(inp.device)[:self._lanes]
+                for lane_stream in self._lane_streams:
+                    # the accumulators were allocated on the caller's stream and are written on these: a hook that is
+                    # dropped without `hessian` ever being read must not hand their memory back while a lane still adds
+                    self._parts.record_stream(lane_stream)
             st = self._lane_streams[lane]
             st.wait_stream(torch.cuda.current_stream(inp.device))   # x was produced there
             x.record_stream(st)
@@ -164,6 +172,8 @@ class HessianHook:
             return True
         pending, self._pending = self._pending, None
         self.tries = ops.hessian_invert_finish(pending, max_try=100)
+        if self.tries != 1:
+            self._generation += 1   # U has been written again: whoever read the first try's U has to start over
         return self.tries == 1
 
 
@@ -292,6 +302,9 @@ def gptq_quant_set(
     side = _side_streams(device)
     per_weight = 1 if scale_bits > 0 else (SINGLE_SLICES if len(weights) == 1 else ROW_SLICES)   # the step of a group's scale grid is a maximum over all rows
 
+    def generation():
+        return hessian_hook._generation if hessian_hook is not None else 0
+
     def enqueue():
         for st in side:
             st.wait_stream(main)   # inputs were produced on the caller's stream; earlier results of ours were read there
@@ -395,9 +408,12 @@ def gptq_quant_set(
         # inversion that was enqueued without one (if it needed another damping, U has just been written
         # again and the set is quantised once more from it)
         while True:
+            read_at = generation()
             jobs, metas = enqueue()
             all_sums = fetch_sums(jobs)
-            if hessian_hook is None or hessian_hook.confirm():
+            if hessian_hook is not None:
+                hessian_hook.confirm()
+            if generation() == read_at:
                 return finish(jobs, metas, all_sums)
 
     def fetch_sums(jobs):
@@ -407,11 +423,18 @@ def gptq_quant_set(
 
     if wait:
         return run_to_the_end()
+    read_at = generation()
     jobs, metas = enqueue()
 
     def settle_now():
+        # The verdict of an inversion enqueued without a wait is read once, by whichever set settles first; every set
+        # that read that first try's U -- this one or one enqueued beside it -- notices by the generation that U has
+        # been written again since and quantises again from the final U.  (The retries write U on the caller's
+        # stream while kernels of a set that has not settled yet may still read it: their results are void anyway.)
         all_sums = fetch_sums(jobs)
-        if hessian_hook is None or hessian_hook.confirm():
+        if hessian_hook is not None:
+            hessian_hook.confirm()
+        if generation() == read_at:
             return finish(jobs, metas, all_sums), True
         return run_to_the_end(), False
 

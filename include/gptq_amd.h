@@ -45,6 +45,11 @@ extern "C" {
 
 typedef void *gq_stream_t;
 
+/* Version of this interface: raised whenever an entry point's argument list changes in place (3: gq_quant_metrics
+ * takes perm_inv; gq_set_quant_super exists).  gq_version() returns the value the library was built with; a caller
+ * built against another header must not go on (the Python binding checks it when it loads the library). */
+#define GQ_ABI_VERSION 3
+
 const char *gq_last_error(void);
 int gq_version(void);
 

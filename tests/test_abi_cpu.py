@@ -53,7 +53,7 @@ def test_grid_options_struct_layout():
 def test_bad_arguments_are_rejected_before_the_device_is_touched():
     from gptq_v2_amd import _lib
     lib = _lib.load()
-    assert lib.gq_version() >= 1
+    assert lib.gq_version() == _lib.ABI_VERSION == int(re.search(r'#define GQ_ABI_VERSION (\d+)', open(HEADER).read()).group(1))
     assert lib.gq_hessian_invert_workspace(0) == 0 and lib.gq_hessian_invert_workspace(4096) > 3 * 4096 * 4096 * 4
     assert lib.gq_quantize_layer_workspace(0, 5) == 0 and lib.gq_quantize_layer_workspace(64, 128) > 0
     assert lib.gq_xtx_accumulate(None, None, 0, 16, 16, 0, 1, None) == -1

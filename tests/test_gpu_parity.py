@@ -250,6 +250,41 @@ def test_quant_set_without_wait_settles_to_the_same_result(amd, gpu, first_try_h
             assert abs(v - rb["metrics"][k]) <= 1e-12 * abs(v), k
 
 
+def test_two_sets_enqueued_against_one_unconfirmed_hook(amd, gpu):
+    """Two gptq_quant_set(wait=False) calls read the U of an inversion whose first try fails.  The verdict is
+    read once (by whichever set settles first), but BOTH sets were computed from the void U: each notices at its
+    own settle() that U has been written again since it read it, and ends with the synchronous result."""
+    c = 256
+    h0 = (_indefinite_hessian(c) * 0.5).float().to(gpu)
+    gen = torch.Generator(device=gpu).manual_seed(8)
+    wa = [(torch.randn(64, c, generator=gen, device=gpu) * 0.02).half()]
+    wb = [(torch.randn(128, c, generator=gen, device=gpu) * 0.02).half()]
+    gs = torch.full([c // 128], 128, dtype=torch.int32)
+    gb = torch.full([c // 128], 4, dtype=torch.int32)
+    kw = dict(gptq_use_kernel=True, gptq_block_sizes=gs, quant_mse=False, save_device=gpu)
+    ref_hook = amd.HessianHook()
+    ref_hook.hessian, ref_hook.n_samples = h0.clone(), 1
+    ref_hook.invert()
+    want_a = amd.gptq_quant_set(wa, ref_hook, gs, gb, **kw)
+    want_b = amd.gptq_quant_set(wb, ref_hook, gs, gb, **kw)
+    hook = amd.HessianHook()
+    hook.hessian, hook.n_samples = h0.clone(), 1
+    hook.invert(wait=False)
+    part_a = amd.gptq_quant_set(wa, hook, gs, gb, wait=False, **kw)
+    part_b = amd.gptq_quant_set(wb, hook, gs, gb, wait=False, **kw)
+    assert part_a.settle() is False          # reads the verdict, makes the remaining tries, quantises again
+    assert part_b.settle() is False          # no verdict left to read -- the generation of U says it all
+    assert part_a.settle() is True and part_b.settle() is True
+    assert hook.tries == ref_hook.tries >= 3
+    for want, got in ((want_a, part_a), (want_b, part_b)):
+        for k, v in want[0]["quant_meta"].items():
+            assert (v is None and got[0]["quant_meta"][k] is None) or torch.equal(v, got[0]["quant_meta"][k]), k
+    # a set enqueued AFTER the retries reads the final U and has nothing to redo
+    part_c = amd.gptq_quant_set(wb, hook, gs, gb, wait=False, **kw)
+    assert part_c.settle() is True
+    assert torch.equal(part_c[0]["quant_meta"]["qweight"], want_b[0]["quant_meta"]["qweight"])
+
+
 def test_invert_llama_size(amd, oracle, gpu):
     """C = 4096 (recursion depth 5) and C = 768 (6 leaves, uneven splits): U^T U H = I."""
     for c, n in ((768, 4096), (4096, 8192)):

@@ -67,3 +67,33 @@ def test_static_workspace_inversion_equals_the_allocating_one(gpu):
                                           1152, 1.0, 0.01, 0, 100, ctypes.byref(tries), stream)
         assert rc == -1 and b"at most 1024" in lib.gq_last_error()
         torch.cuda.synchronize()
+
+
+def test_static_workspace_inversion_allocates_no_device_memory(gpu):
+    """What the entry point exists for: between a warm-up call and the calls that follow, the device's free memory
+    does not move (hipMemGetInfo through torch.cuda.mem_get_info; torch's own caching allocator is kept out of it
+    by preparing every tensor beforehand)."""
+    from gptq_v2_amd import _lib
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(gpu):
+        cases = []
+        for c in (1024, 512, 1024):
+            h = _hessian(c, 77 + c, gpu)
+            cases.append((c, h, torch.empty(c, c, device=gpu), torch.empty(c, dtype=torch.int32, device=gpu),
+                          torch.empty(c, dtype=torch.int32, device=gpu)))
+        tries = ctypes.c_int(0)
+
+        def call(c, h, u, perm, perm_inv):
+            rc = lib.gq_hessian_invert_static(p(h), p(u), p(perm), p(perm_inv), c, 4.0, 0.01, 1, 100, ctypes.byref(tries), stream)
+            assert rc == 0, lib.gq_last_error()
+
+        call(*cases[0])                      # warm-up: code objects loaded, the symbol's address resolved
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info(gpu)
+        for case in cases[1:]:
+            call(*case)
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(gpu)
+        assert free_after == free_before
