@@ -172,7 +172,7 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
             hook.hessian
         if world > 1:
             with phases["allreduce"]:
-                hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
+                hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples, n_total=args.samples)
         with phases["invert"]:
             # enqueued without a host round trip; gptq_quant_set reads the verdict with its metrics
             hook.invert(damp_ratio=1e-2, act_order=True, wait=False)
@@ -186,38 +186,44 @@ def run_block(torch, amd, gd, sets, xs, ws, args, phases, rank, world, flops):
             part = amd.gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=None, gptq_use_kernel=True,
                                       gptq_block_sizes=gs, quant_symmetric=False, quant_mse=False, save_device=dev,
                                       wait=False)
-        if world > 1:
-            part.settle()   # the gather over ranks combines the shards' metrics: they have to be there
         while True:
-            by_index = {i: res for (i, _), res in zip(mine, part)}
-            set_flops = consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, by_index, hook, gs, gb)
+            set_flops = consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, mine, part, hook, gs, gb)
             # metrics and the verdict of the inversion's first try, read while the replay runs; if that try had
             # failed the set has been quantised again from the final U and its consumers run once more
             if part.settle():
                 break
         flops[0] += set_flops
-        del part, by_index, hook
+        del part, hook
 
 
-def consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, by_index, hook, gs, gb):
+def consume_set(torch, amd, gd, args, phases, world, dev, c, x, weights, mine, part, hook, gs, gb):
     """Reconstruct, pack and replay the Linears of one set; returns the replay's flops."""
     batch = args.batch
     done = 0.0
     dense, packed = [], []
-    for i, w in enumerate(weights):
-        res = by_index.get(i)
-        if world > 1:
-            with phases["allgather"]:
-                fields = {"qscale": None, "sscale": None, "scale_bit_width": None,
-                          "perm_inv": hook.perm_inv.to(torch.int16), "group_sizes": gs.to(torch.int16).to(dev),
-                          "group_bit_widths": gb.to(torch.uint8).to(dev)}
-                res = gd.gather_quant_result(res, fields, w.shape[0], c, w.dtype, dev)
-        meta = res["quant_meta"]
+    if world > 1:
+        # one all-gather (levels two to a byte, scales, zero points) and one all-reduce (metric sums) per set, on the
+        # device: the host does not wait here
+        with phases["allgather"]:
+            fields = {"qscale": None, "sscale": None, "scale_bit_width": None, "perm_inv": hook.perm_inv.to(torch.int16),
+                      "group_sizes": gs.to(torch.int16).to(dev), "group_bit_widths": gb.to(torch.uint8).to(dev)}
+            local_meta = [None] * len(weights)
+            local_sums = torch.zeros(len(weights), 4, dtype=torch.float64, device=dev)
+            mine_sums = part.metric_sums() if mine else None
+            for k, ((i, _), res) in enumerate(zip(mine, part)):
+                local_meta[i] = res["quant_meta"]
+                local_sums[i] = mine_sums[k]
+            parts, _sums = gd.gather_quant_set(local_meta, local_sums, [w.shape[0] for w in weights], c, len(gs),
+                                               weights[0].dtype, dev, args.bits)
+            metas = [dict(fields, **p_) for p_ in parts]
+    else:
+        metas = [res["quant_meta"] for res in part]
+    for meta in metas:
         with phases["reconstruct"]:
             dense.append(amd.quant.reconstruct_weight(meta, torch.float16, dev))
         with phases["pack"]:
             packed.append(amd.QuantLinear.from_quant_meta(meta, dev, validate=False, has_perm=True, dense3=args.bits == 3))
-        del meta, res
+    del metas
     # replay (llama.py:176-177).  Dense: the Linears of a set read the same input, so up to MERGE_ROWS
     # rows of reconstructed weights are stacked and replayed in one launch per batch (each output row
     # is the same dot product either way).  Packed: one gather of the batch into act-order per set,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "gq_pack_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "gq_unpack_rows": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "gq_permute_columns": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gq_pack_lower": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "gq_unpack_lower": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "gq_w4a16_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_void_p]),
     "gq_w4a16_gemm_dt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,

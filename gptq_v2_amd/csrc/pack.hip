@@ -390,6 +390,73 @@ extern "C" int gq_dequantize(const uint8_t *qweight, const void *scale, const ui
     return GQ_OK;
 }
 
+// ---- lower triangle of a symmetric fp32 matrix <-> one flat buffer --------------------------------
+// Element (r, c <= r) lies at r (r + 1) / 2 + c.  What travels between GPUs when Hessians are summed over ranks:
+// half the matrix instead of all of it.
+namespace {
+
+// one 64 x 64 tile (tr >= tc) per workgroup; thread = (row in groups of 4, column)
+__global__ __launch_bounds__(256) void pack_lower_kernel(const float *__restrict__ h, int64_t c, float *__restrict__ flat)
+{
+    const int64_t tr = blockIdx.y, tc = blockIdx.x;
+    if (tc > tr) return;
+    const int j = threadIdx.x & 63;
+    const int64_t col = tc * 64 + j;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int64_t row = tr * 64 + (threadIdx.x >> 6) + 4 * pass;
+        if (row < c && col <= row) flat[row * (row + 1) / 2 + col] = h[row * c + col];
+    }
+}
+
+// the same tile back, and its mirror image above the diagonal: H comes out exactly symmetric
+__global__ __launch_bounds__(256) void unpack_lower_kernel(const float *__restrict__ flat, int64_t c, float *__restrict__ h)
+{
+    __shared__ float tile[64][65];
+    const int64_t tr = blockIdx.y, tc = blockIdx.x;
+    if (tc > tr) return;
+    const int j = threadIdx.x & 63;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int i = (threadIdx.x >> 6) + 4 * pass;
+        const int64_t row = tr * 64 + i, col = tc * 64 + j;
+        tile[i][j] = (row < c && col <= row) ? flat[row * (row + 1) / 2 + col] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int i = (threadIdx.x >> 6) + 4 * pass;
+        const int64_t row = tr * 64 + i, col = tc * 64 + j;
+        if (row < c && col < c) {
+            if (tr != tc) h[row * c + col] = tile[i][j];
+            else h[row * c + col] = j <= i ? tile[i][j] : tile[j][i];
+        }
+        // the mirrored tile: element (tc * 64 + i, tr * 64 + j) = tile[j][i]
+        const int64_t mrow = tc * 64 + i, mcol = tr * 64 + j;
+        if (tr != tc && mrow < c && mcol < c) h[mrow * c + mcol] = tile[j][i];
+    }
+}
+
+}  // namespace
+
+extern "C" int gq_pack_lower(const float *hessian, int64_t c, float *flat, gq_stream_t stream)
+{
+    GQ_REQUIRE(hessian && flat && c > 0 && c <= (1 << 22), "gq_pack_lower: bad argument");
+    const unsigned nt = (unsigned)gq_cdiv(c, 64);
+    hipLaunchKernelGGL(pack_lower_kernel, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, hessian, c, flat);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_unpack_lower(const float *flat, int64_t c, float *hessian, gq_stream_t stream)
+{
+    GQ_REQUIRE(hessian && flat && c > 0 && c <= (1 << 22), "gq_unpack_lower: bad argument");
+    const unsigned nt = (unsigned)gq_cdiv(c, 64);
+    hipLaunchKernelGGL(unpack_lower_kernel, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, flat, c, hessian);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
 extern "C" int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t c, void *x_out, gq_stream_t stream)
 {
     GQ_REQUIRE(m >= 0 && c > 0 && c <= 80 * 1024, "gq_permute_columns: bad shape");

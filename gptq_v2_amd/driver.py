@@ -66,7 +66,7 @@ class _HostCopier:
     names work enqueued earlier).  Measured against the alternative of ordering the copies on the last side
     stream itself (GQ_COPIER_STREAM=side; random-init blocks of Llama-2-7B size, 128 x 2048 tokens): 0.212 s per
     block with the stream of its own, 0.226 s on the side stream, where the third Linear of the next q/k/v set
-    queues behind the copy of down_proj's results.
+    queues behind the copy of down_proj's results."""
 
     def __init__(self, device: torch.device) -> None:
         from concurrent.futures import ThreadPoolExecutor
@@ -204,6 +204,7 @@ def quantize_llama(
         sb, se = gd.sample_shard(len(encodings), rank, world)
         if se == sb:
             raise ValueError(f"{len(encodings)} calibration sequences cannot be split over {world} ranks")
+        n_global = len(encodings)
         encodings = encodings[sb:se]
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
@@ -220,7 +221,8 @@ def quantize_llama(
         """invert + quantise + put the results into the block; the Hessian is complete"""
         mods = [_submodule(block, nm) for nm in names]
         if world > 1:
-            hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples)
+            # the global count is known here (this function made the shards): no collective and no wait for it
+            hook.n_samples = gd.allreduce_hessian(hook.hessian, hook.n_samples, n_total=n_global)
         # no host round trip between inversion and column loops (gptq_quant_set settles it), unless a
         # callback wants to look at the finished hook first
         hook.invert(damp_ratio=damp_ratio, act_order=act_order, wait=on_set is not None)
@@ -243,19 +245,26 @@ def quantize_llama(
         part = gptq_quant_set([w for _, w in mine], hook, gs, gb, scale_bit_width=sbw, gptq_use_kernel=True,
                               gptq_block_sizes=gs, quant_symmetric=symmetric, quant_mse=quant_mse,
                               save_device=device, wait=False)
-        if world > 1:
-            part.settle()   # the gather over ranks combines the shards' metrics: they have to be there
+        sums = None
         while True:
             if world > 1:
-                by_index = {i: res for (i, _), res in zip(mine, part)}
+                # one all-gather of the set's levels (two to a byte), scales and zero points and one all-reduce of
+                # its metric sums, all on the device: like the single-GPU flow, nothing waits for the host here
                 c_ = weights[0].shape[1]
                 fields = {"qscale": None, "sscale": None, "scale_bit_width": None if sbw is None else sbw.to(torch.uint8).to(device),
                           "perm_inv": (hook.perm_inv.to(torch.int16) if hook.perm_inv is not None
                                        else torch.arange(c_, dtype=torch.int16, device=device)),
                           "group_sizes": gs.to(dtype=torch.int16, device=device),
                           "group_bit_widths": gb.to(dtype=torch.uint8, device=device)}
-                outs = [gd.gather_quant_result(by_index.get(i), fields, w.shape[0], c_, w.dtype, device)
-                        for i, w in enumerate(weights)]
+                local_meta = [None] * len(weights)
+                local_sums = torch.zeros(len(weights), 4, dtype=torch.float64, device=device)
+                mine_sums = part.metric_sums() if mine else None
+                for k, ((i, _), res) in enumerate(zip(mine, part)):
+                    local_meta[i] = res["quant_meta"]
+                    local_sums[i] = mine_sums[k]
+                parts, sums = gd.gather_quant_set(local_meta, local_sums, [w.shape[0] for w in weights], c_, len(gs),
+                                                  weights[0].dtype, device, bits)
+                outs = [{"quant_meta": dict(fields, **p_), "metrics": None} for p_ in parts]
             else:
                 outs = list(part)
             layers = []
@@ -271,6 +280,10 @@ def quantize_llama(
                     layers.append(reconstruct_weight(meta, dtype, device))
             if part.settle():
                 break
+        if world > 1:
+            rows_of = sums.tolist()   # the host has just waited for this set in settle(): the sums are there
+            for res, w, row in zip(outs, weights, rows_of):
+                res["metrics"] = gd.metrics_from_sums(row, w.shape[0], w.shape[1], w.dtype)
         for name, mod, res, layer in zip(names, mods, outs, layers):
             canonical = f"model.layers.{gi}.{name}"
             results["metrics"][canonical] = res["metrics"]

@@ -400,7 +400,7 @@ def gptq_quant_set(
                 # the reference takes this mean in the weight's 16-bit dtype (gptq_py.py:237)
                 "l2.0_norm": torch.tensor(sums[3] / n, dtype=torch.float64).to(weight.dtype).item(),
             }
-            out.append({"quant_meta": metas[wi], "metrics": metrics})
+            out.append({"quant_meta": metas[wi], "metrics": metrics, "_metric_sums": sums})
         return out
 
     def run_to_the_end():
@@ -438,16 +438,35 @@ def gptq_quant_set(
             return finish(jobs, metas, all_sums), True
         return run_to_the_end(), False
 
-    return QuantSetResult([{"quant_meta": m, "metrics": None} for m in metas], settle_now)
+    def device_sums():
+        out = torch.zeros(len(weights), 4, dtype=torch.float64, device=device)
+        here = torch.cuda.current_stream(device)
+        for j in jobs:
+            here.wait_event(j[3])
+            out[j[0]] += j[2]
+        return out
+
+    return QuantSetResult([{"quant_meta": m, "metrics": None} for m in metas], settle_now, device_sums)
 
 
 class QuantSetResult(list):
     """What ``gptq_quant_set(wait=False)`` returns: the per-weight result dictionaries, with ``metrics``
     still None and the tensors of ``quant_meta`` valid in stream order."""
 
-    def __init__(self, items, settle_now) -> None:
+    def __init__(self, items, settle_now, device_sums=None) -> None:
         super().__init__(items)
         self._settle_now = settle_now
+        self._device_sums = device_sums
+
+    def metric_sums(self) -> torch.Tensor:
+        """(len(self), 4) float64 on the device: per weight the four sums behind the metrics (squared scaled errors,
+        squared weights over diag(U), squared rounding errors, squared weights -- sums, not means), valid on the
+        current stream without a wait of the host.  For callers that combine shards of a layer on the device
+        (``dist.gather_quant_set``) before anything is settled."""
+        if self._settle_now is not None:
+            return self._device_sums()
+        dev = self[0]["quant_meta"]["qweight"].device if len(self) else "cpu"
+        return torch.tensor([r["_metric_sums"] for r in self], dtype=torch.float64, device=dev).reshape(len(self), 4)
 
     def settle(self) -> bool:
         """Waits for the device and fills in ``metrics``.  Returns False if the inversion behind the set had

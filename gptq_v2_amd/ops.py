@@ -371,6 +371,30 @@ def unpack_rows(packed: torch.Tensor, bits: int, n: int, layout: int = PACK_STRE
     return out
 
 
+def pack_lower(hessian: torch.Tensor, flat: torch.Tensor) -> None:
+    """flat[r (r + 1) / 2 + c] = hessian[r][c] for c <= r (fp32, C x C); flat has at least C (C + 1) / 2 elements."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(flat, "flat", torch.float32, 1)
+    c = hessian.shape[0]
+    if hessian.shape[1] != c or flat.numel() < c * (c + 1) // 2:
+        raise ValueError("pack_lower: a square matrix and a buffer of C (C + 1) / 2 elements")
+    with torch.cuda.device(hessian.device):
+        rc = _lib.load().gq_pack_lower(_p(hessian), c, _p(flat), _stream(hessian))
+    _lib.check(rc, "gq_pack_lower")
+
+
+def unpack_lower(flat: torch.Tensor, hessian: torch.Tensor) -> None:
+    """Inverse of pack_lower; the upper triangle is written as the mirror image."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(flat, "flat", torch.float32, 1)
+    c = hessian.shape[0]
+    if hessian.shape[1] != c or flat.numel() < c * (c + 1) // 2:
+        raise ValueError("unpack_lower: a square matrix and a buffer of C (C + 1) / 2 elements")
+    with torch.cuda.device(hessian.device):
+        rc = _lib.load().gq_unpack_lower(_p(flat), c, _p(hessian), _stream(hessian))
+    _lib.check(rc, "gq_unpack_lower")
+
+
 def permute_columns(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     _check(x, "x", None, 2)
     _check(perm, "perm", torch.int32, 1)

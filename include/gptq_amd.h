@@ -268,6 +268,13 @@ int gq_pack_rows(const uint8_t *values, int64_t rows, int64_t n, int bits, int l
 int gq_unpack_rows(const uint32_t *packed, int64_t rows, int64_t n, int bits, int layout,
                    uint8_t *values, gq_stream_t stream);
 
+/* The lower triangle of a symmetric C x C fp32 matrix as one flat buffer of C (C + 1) / 2 floats -- element
+ * (r, c <= r) at r (r + 1) / 2 + c -- and back, the upper triangle restored as the mirror image (exactly
+ * symmetric).  What is exchanged when the Hessians of several GPUs are summed: half the bytes of the matrix.
+ * No reference counterpart (the reference is single-GPU, parse_args.py:53-55). */
+int gq_pack_lower(const float *hessian, int64_t c, float *flat, gq_stream_t stream);
+int gq_unpack_lower(const float *flat, int64_t c, float *hessian, gq_stream_t stream);
+
 /* x_out[m][j] = x_in[m][perm[j]] for 16-bit elements (activation gather for act-order). */
 int gq_permute_columns(const void *x_in, const int32_t *perm, int64_t m, int64_t c, void *x_out,
                        gq_stream_t stream);

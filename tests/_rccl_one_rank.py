@@ -39,6 +39,25 @@ def main():
     res = gd.gather_quant_result({"quant_meta": meta, "metrics": {"gptq_error": 1.5, "gptq_norm": 2.5, "l2.0_error": 3.5,
                                                                   "l2.0_norm": 0.25}}, fields, rows, 64, torch.float16, dev)
     assert torch.equal(res["quant_meta"]["qweight"], parts["qweight"]) and res["metrics"]["gptq_error"] == 1.5
+    # the triangle kernels on their own: pack -> unpack restores a symmetric matrix bit for bit, whatever the size
+    for c in (5, 64, 100, 1000):
+        a = torch.randn(c, c, generator=gen, device=dev)
+        h = torch.tril(a) + torch.tril(a, -1).t()
+        flat = gd.pack_lower(h, multiple=8)
+        assert flat.numel() % 8 == 0 and flat.numel() - c * (c + 1) // 2 < 8
+        r_, c_ = torch.tril_indices(c, c, device=dev)
+        assert torch.equal(flat[: c * (c + 1) // 2], h[r_, c_])
+        out = torch.full_like(h, float("nan"))
+        gd.unpack_lower(flat, out)
+        assert torch.equal(out, h)
+    # the per-set gather on device tensors
+    heights = [128, 200]
+    full = [{"qweight": torch.randint(0, 16, (h_, 64), generator=gen, device=dev, dtype=torch.uint8),
+             "scale": torch.rand(h_, 2, generator=gen, device=dev).half(),
+             "qzero": torch.randint(0, 16, (h_, 2), generator=gen, device=dev, dtype=torch.uint8)} for h_ in heights]
+    sums = torch.arange(8, dtype=torch.float64, device=dev).reshape(2, 4)
+    got_parts, got_sums = gd.gather_quant_set(full, sums.clone(), heights, 64, 2, torch.float16, dev, bits=4)
+    assert all(torch.equal(got_parts[i][k], full[i][k]) for i in range(2) for k in full[i]) and torch.equal(got_sums, sums)
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("rccl one-rank ok")

@@ -61,6 +61,29 @@ def _worker(rank, ws, port, n_rows):
     assert res["quant_meta"]["qweight"].shape == (rows, cols) and int(res["quant_meta"]["qweight"].sum()) == 7 * rows * cols
     assert torch.equal(res["quant_meta"]["perm_inv"], fields["perm_inv"])
     assert res["metrics"] == {"gptq_error": 1.0, "gptq_norm": 2.0, "l2.0_error": 3.0, "l2.0_norm": 4.0}
+
+    # a set of two Linears of different heights in ONE all-gather: levels two to a byte, 16-bit scales, zero
+    # points; metric sums in one all-reduce.  n_total spares the Hessian reduce its count collective.
+    torch.manual_seed(3)
+    heights, cols, g = [128, 192], 12, 3
+    full = [{"qweight": torch.randint(0, 16, (h_, cols), dtype=torch.uint8), "scale": torch.rand(h_, g).half(),
+             "qzero": torch.randint(0, 16, (h_, g), dtype=torch.uint8)} for h_ in heights]
+    locals_, sums = [], torch.zeros(2, 4, dtype=torch.float64)
+    for i, h_ in enumerate(heights):
+        rb, re = gd.row_shard(h_, rank, ws)
+        locals_.append({k: v[rb:re] for k, v in full[i].items()} if re > rb else None)
+        sums[i] = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (re - rb)
+    parts, total = gd.gather_quant_set(locals_, sums, heights, cols, g, torch.float16, "cpu", bits=4)
+    for i, h_ in enumerate(heights):
+        for k in ("qweight", "scale", "qzero"):
+            assert torch.equal(parts[i][k], full[i][k]), (i, k)
+        assert total[i].tolist() == [1.0 * h_, 2.0 * h_, 3.0 * h_, 4.0 * h_]
+    h = torch.eye(8) * (rank + 1)
+    assert gd.allreduce_hessian(h, 5, n_total=10) == 10 and torch.equal(h, torch.eye(8) * 3)
+    q8 = torch.randint(0, 256, (4, 6), dtype=torch.uint8)
+    assert torch.equal(gd.unpack_levels(gd.pack_levels(q8, 8), 8, 6), q8) and gd.pack_levels(q8, 8).shape == (4, 6)
+    q4 = torch.randint(0, 16, (4, 6), dtype=torch.uint8)
+    assert gd.pack_levels(q4, 4).shape == (4, 3) and torch.equal(gd.unpack_levels(gd.pack_levels(q4, 4), 4, 6), q4)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,7 +112,7 @@ def test_pack_lower_roundtrip():
         a = torch.randn(c, c)
         h = torch.tril(a) + torch.tril(a, -1).t()
         flat = gd.pack_lower(h, multiple=8)
-        assert flat.numel() % 8 == 0 and flat.numel() < c * c * 0.75 + 64
+        assert flat.numel() % 8 == 0 and c * (c + 1) // 2 <= flat.numel() < c * (c + 1) // 2 + 8
         out = torch.full_like(h, float("nan"))
         gd.unpack_lower(flat, out)
         assert torch.equal(out, h)
