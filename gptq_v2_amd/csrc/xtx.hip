@@ -357,7 +357,8 @@ __device__ unsigned long long *g_xtx_trace = nullptr;
 template <int DTYPE>
 __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, const unsigned short *__restrict__ x,
                                                      int hidden, int n_ktiles_all, uint32_t tile_order,
-                                                     int n_blocks, int mirror, int n_tiles, int n_splits, int64_t part_stride)
+                                                     int n_blocks, int mirror, int n_tiles, int n_splits, int64_t part_stride,
+                                                     int n_full, int tail_splits, float *__restrict__ tail_buf)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef GQ_XTX_TRACE
@@ -370,23 +371,47 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     const int lane = tid & 63;
     int bid;
     {
-        const int orig = blockIdx.x;
+        // workgroups go to the XCDs round-robin; each XCD takes one contiguous stretch of the order.  With a tail
+        // split the whole tiles and the tail runs are two such ranges (n_full is a multiple of 8), so that every
+        // XCD gets its share of the short workgroups
+        const int base = (tail_splits > 0 && (int)blockIdx.x >= n_full) ? n_full : 0;
+        const int count = tail_splits > 0 ? (base ? n_blocks - n_full : n_full) : n_blocks;
+        const int orig = blockIdx.x - base;
         const int xcd = orig & 7;
-        const int q = n_blocks >> 3, r = n_blocks & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int q = count >> 3, r = count & 7;
+        bid = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     // token split: workgroup (tile, split) adds the products of its share of the k-steps into partial
-    // Hessian `split` (part_stride floats apart); the caller sums the parts
-    const int split = bid / n_tiles;
+    // Hessian `split` (part_stride floats apart); the caller sums the parts.
+    // Tail split (tail_splits > 0, n_splits == 1): the first n_full tiles of the order -- whole rounds of one
+    // workgroup per CU -- are taken whole; the tiles behind them, which would fill only part of a last round, are
+    // cut into tail_splits token runs each, workgroups of one run next to each other, and accumulate into tile-sized
+    // buffers of their own (tail_buf[run][tile]); gq_xtx_fold_tail adds those into H.
+    int split, n_sp, tile_idx;
+    const bool tail = tail_splits > 0 && bid >= n_full;
+    if (tail) {
+        const int n_tail = n_tiles - n_full, idx = bid - n_full;
+        split = idx / n_tail;
+        tile_idx = n_full + (idx - split * n_tail);
+        n_sp = tail_splits;
+    } else {
+        split = bid / n_tiles;
+        tile_idx = bid - split * n_tiles;
+        n_sp = n_splits;
+    }
     int ti, tj;
-    xtx_tile_of(bid - split * n_tiles, tile_order, ti, tj);
+    xtx_tile_of(tile_idx, tile_order, ti, tj);
     const int m0 = ti * T2, n0 = tj * T2;
     const int64_t ld = hidden;
-    const int k_begin = (int)((int64_t)n_ktiles_all * split / n_splits);
-    const int n_ktiles = (int)((int64_t)n_ktiles_all * (split + 1) / n_splits) - k_begin;
+    const int k_begin = (int)((int64_t)n_ktiles_all * split / n_sp);
+    const int n_ktiles = (int)((int64_t)n_ktiles_all * (split + 1) / n_sp) - k_begin;
     if (n_ktiles == 0) return;   // uniform over the workgroup
     x += (int64_t)k_begin * BK2 * ld;
-    hess += (int64_t)split * part_stride;
+    // where the tile's sums go: into H at (m0, n0), or into the tail buffer's own 256 x 256 piece
+    float *__restrict__ out = tail ? tail_buf + ((int64_t)split * (n_tiles - n_full) + (tile_idx - n_full)) * (T2 * T2)
+                                   : hess + (int64_t)split * part_stride;
+    const int64_t out_ld = tail ? T2 : ld;
+    const int om0 = tail ? 0 : m0, on0 = tail ? 0 : n0;
 
     // 16 x 16 x 32 blocks: the 16 lanes of group g hold the 16 columns of a block for tokens 8 g .. 8 g + 7
     // of the 32-token step (two transposing reads of 4 tokens each)
@@ -507,28 +532,28 @@ __global__ __launch_bounds__(512) void xtx256_kernel(float *__restrict__ hess, c
     // H[tile] += acc.  Register e of a lane is row 4 * (lane >> 4) + e, column lane & 15 of the 16 x 16
     // block, so in the mirrored tile the four registers are four consecutive floats of one row: one
     // 16-byte store.  The loads of four blocks are issued together.
-    const bool do_mirror = mirror && (ti != tj);
+    const bool do_mirror = mirror && (ti != tj) && !tail;   // (a tail tile's mirror image is written by the fold)
     const int lrow = 4 * (lane >> 4), lcol = lane & 15;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         float old[4][4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const float *p0 = hess + (int64_t)(m0 + wr * 128 + a * 16 + lrow) * ld + n0 + wc * 64 + b * 16 + lcol;
+            const float *p0 = out + (int64_t)(om0 + wr * 128 + a * 16 + lrow) * out_ld + on0 + wc * 64 + b * 16 + lcol;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) old[b][e] = p0[(int64_t)e * ld];
+            for (int e = 0; e < 4; ++e) old[b][e] = p0[(int64_t)e * out_ld];
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int row0 = m0 + wr * 128 + a * 16 + lrow, col = n0 + wc * 64 + b * 16 + lcol;
-            float *p0 = hess + (int64_t)row0 * ld + col;
+            const int row0 = om0 + wr * 128 + a * 16 + lrow, col = on0 + wc * 64 + b * 16 + lcol;
+            float *p0 = out + (int64_t)row0 * out_ld + col;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 old[b][e] += acc[a][b][e];
-                p0[(int64_t)e * ld] = old[b][e];
+                p0[(int64_t)e * out_ld] = old[b][e];
             }
             if (do_mirror)
-                *reinterpret_cast<f32x4 *>(hess + (int64_t)col * ld + row0) = f32x4{old[b][0], old[b][1], old[b][2], old[b][3]};
+                *reinterpret_cast<f32x4 *>(out + (int64_t)col * out_ld + row0) = f32x4{old[b][0], old[b][1], old[b][2], old[b][3]};
         }
     }
 #ifdef GQ_XTX_TRACE
@@ -638,21 +663,65 @@ int launch_mfma(float *hess, const unsigned short *x, int64_t n_tokens, int64_t 
     return GQ_OK;
 }
 
+// The tail split of a hidden size: tiles = n_full + n_tail, the n_tail tiles of the partly filled last round in
+// `splits` token runs each (0: no tail split).  Measured: a launch costs its ROUNDS of one workgroup per CU, not its
+// tiles (32768 tokens: hidden 9216 = 666 tiles 2.63 ms, 9728 = 741 tiles 2.57 ms, 11008 = 946 tiles 3.35 ms, 11264 =
+// 990 tiles 3.40 ms: 0.84-0.87 ms per started round), so 178 tiles in a fourth round cost as much as 256; cut into 4
+// runs they are 712 workgroups of a quarter of the length, three short rounds: 3.75 rounds instead of 4.
+struct XtxTail { int n_full, n_tail, splits; };
+
+XtxTail xtx_tail_plan(int64_t hidden, int compute_lower_only)
+{
+    static const int off = [] { const char *e = getenv("GQ_XTX_TAIL"); return e && e[0] == '0' ? 1 : 0; }();
+    XtxTail none{0, 0, 0};
+    if (off || hidden % T2 || hidden < 3584) return none;
+    const int64_t nt = hidden / T2, tiles = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
+    if (tiles <= 256 || tiles % 256 == 0 || nt >= 65536) return none;
+    const int n_tail = (int)(tiles % 256);
+    int best = 0;
+    double best_cost = 0.9;   // of a full round; every extra run costs one more epilogue per tile (~2 % of a tile)
+    for (int sp = 2; sp <= 8; ++sp) {
+        const double cost = (double)gq_cdiv((int64_t)n_tail * sp, 256) / sp + 0.02 * (sp - 1);
+        if (cost < best_cost) {
+            best = sp;
+            best_cost = cost;
+        }
+    }
+    if (!best) return none;
+    return XtxTail{(int)(tiles - n_tail), n_tail, best};
+}
+
 template <int DTYPE>
 int launch_mfma256(float *hess, const unsigned short *x, int64_t n_tokens, int64_t hidden, int compute_lower_only,
-                   int mirror, hipStream_t stream, int64_t &done, int n_splits = 1, int64_t part_stride = 0)
+                   int mirror, hipStream_t stream, int64_t &done, int n_splits = 1, int64_t part_stride = 0,
+                   float *tail_buf = nullptr)
 {
     const int nt = (int)(hidden / T2);
     const int n_ktiles = (int)(n_tokens / BK2);
     GQ_REQUIRE(nt < 65536, "gq_xtx_accumulate: hidden size too large");
     const int n_blocks = compute_lower_only ? nt * (nt + 1) / 2 : nt * nt;
+    if (tail_buf) {
+        const XtxTail plan = xtx_tail_plan(hidden, compute_lower_only);
+        GQ_REQUIRE(plan.splits > 0 && n_splits == 1, "gq_xtx_accumulate_tail: no tail split for hidden size %lld", (long long)hidden);
+        // a short call (fewer than 64 k-steps per run) leaves the tail tiles whole: one run, still into the buffer
+        const int runs = std::max(1, std::min(plan.splits, n_ktiles / 64));
+        const uint32_t table = xtx_order(nt, xtx_super_tile(6), compute_lower_only);
+        auto kern = xtx256_kernel<DTYPE>;
+        const int grid = plan.n_full + plan.n_tail * runs;
+        GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles, table, grid, mirror,
+                           n_blocks, 1, (int64_t)0, plan.n_full, runs, tail_buf);
+        GQ_LAUNCH_CHECK();
+        done = (int64_t)n_ktiles * BK2;
+        return GQ_OK;
+    }
     // 6 x 6 super-tiles: the ~32 tiles an XCD runs at a time (one per CU) then span about 12 column
     // panels of X instead of 64, and the XCD's L2 serves the rest (measured: fewest memory-side bytes)
     const uint32_t table = xtx_order(nt, xtx_super_tile(6), compute_lower_only);
     auto kern = xtx256_kernel<DTYPE>;
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XTX2_LDS));
     hipLaunchKernelGGL(kern, dim3(n_blocks * n_splits), dim3(512), XTX2_LDS, stream, hess, x, (int)hidden, n_ktiles, table,
-                       n_blocks * n_splits, mirror, n_blocks, n_splits, part_stride);
+                       n_blocks * n_splits, mirror, n_blocks, n_splits, part_stride, n_blocks, 0, (float *)nullptr);
     GQ_LAUNCH_CHECK();
     done = (int64_t)n_ktiles * BK2;
     return GQ_OK;
@@ -687,17 +756,12 @@ int launch_xtx(float *hess, const unsigned short *x, int64_t n_tokens, int64_t h
         int rc;
         int variant = xtx_variant();
         if (variant < 0) {
-            // 256 x 256 tiles at one workgroup per CU, or 128 x 128 tiles at two: whichever needs less
-            // time by a round count weighted with the measured time of a round (a full round of 256
-            // large tiles ~1.0, a round filling under 60 % of the CUs ~0.8, a round of 512 small tiles ~0.55)
-            variant = 4;
-            if (hidden % T2 == 0) {
-                const int64_t nt2 = hidden / T2, t256 = compute_lower_only ? nt2 * (nt2 + 1) / 2 : nt2 * nt2;
-                const int64_t nt1 = hidden / TM, t128 = compute_lower_only ? nt1 * (nt1 + 1) / 2 : nt1 * nt1;
-                const int64_t r256 = gq_cdiv(t256, 256), r128 = gq_cdiv(t128, 512);
-                const int64_t c256 = r256 * (t256 * 10 <= r256 * 256 * 6 ? 80 : 100), c128 = r128 * 55;
-                if (c256 < c128) variant = 5;
-            }
+            // 256 x 256 tiles at one workgroup per CU, or 128 x 128 tiles at two.  Measured per 32768-token call
+            // (tools/bench_xtx_variants.py, ms, 256-tiles | 128-tiles): hidden 768..3072 0.61-0.64 | 0.46-0.49 (at most
+            // 78 large tiles: most CUs idle), 3584 0.70 | 0.74, 4096 0.70 | 0.82, 5120 0.89 | 1.55, 8192 2.36 | 2.84,
+            // 10240 3.30 | 4.99, 13824 5.27 | 8.95, 28672 23.1 | 43.9.  (A round-count model weighted with round times
+            // measured on an earlier kernel chose the small tiles at 8192-11520 and lost 17-35 % there.)
+            variant = (hidden % T2 == 0 && hidden >= 3584) ? 5 : 4;
         }
         switch (variant) {
         case 0: rc = launch_mfma<DTYPE, 64, 2>(hess, x, n_tokens, hidden, compute_lower_only, mirror, stream, done); break;
@@ -828,6 +892,105 @@ __global__ void xtx_fold_kernel(float *__restrict__ parts, int n_parts, int64_t 
     }
 }
 }  // namespace
+
+namespace {
+// H[tile] += tail_buf[0][t] + tail_buf[1][t] + ... (in index order), the buffers cleared, and the tile's mirror image
+// written from the result: one workgroup per tail tile, 64 x 64 pieces through LDS for the transposed write
+__global__ __launch_bounds__(256) void xtx_fold_tail_kernel(float *__restrict__ hess, float *__restrict__ tail_buf, int hidden,
+                                                            uint32_t tile_order, int n_full, int n_tail, int splits, int mirror)
+{
+    __shared__ float piece[64][65];
+    const int t = blockIdx.x;
+    int ti, tj;
+    xtx_tile_of(n_full + t, tile_order, ti, tj);
+    const int64_t ld = hidden;
+    const int64_t m0 = (int64_t)ti * T2, n0 = (int64_t)tj * T2;
+    const bool do_mirror = mirror && ti != tj;
+    const int r = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;   // 16 rows x 16 float4 per turn
+    for (int sr = 0; sr < 4; ++sr)
+        for (int sc = 0; sc < 4; ++sc) {
+            if (do_mirror) __syncthreads();
+#pragma unroll
+            for (int turn = 0; turn < 4; ++turn) {
+                const int row = sr * 64 + turn * 16 + r, col = sc * 64 + c4;
+                float *ph = hess + (m0 + row) * ld + n0 + col;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ph);
+                for (int p = 0; p < splits; ++p) {
+                    f32x4 *pb = reinterpret_cast<f32x4 *>(tail_buf + ((int64_t)p * n_tail + t) * (T2 * T2) + row * T2 + col);
+                    v += *pb;
+                    *pb = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4 *>(ph) = v;
+                if (do_mirror) {
+                    piece[turn * 16 + r][c4 + 0] = v[0];
+                    piece[turn * 16 + r][c4 + 1] = v[1];
+                    piece[turn * 16 + r][c4 + 2] = v[2];
+                    piece[turn * 16 + r][c4 + 3] = v[3];
+                }
+            }
+            if (do_mirror) {
+                __syncthreads();
+#pragma unroll
+                for (int turn = 0; turn < 4; ++turn) {
+                    const int mr = turn * 16 + r;   // row of the mirrored piece = column of the piece
+                    const f32x4 v = f32x4{piece[c4 + 0][mr], piece[c4 + 1][mr], piece[c4 + 2][mr], piece[c4 + 3][mr]};
+                    *reinterpret_cast<f32x4 *>(hess + (n0 + sc * 64 + mr) * ld + m0 + sr * 64 + c4) = v;
+                }
+            }
+        }
+}
+}  // namespace
+
+extern "C" size_t gq_xtx_tail_workspace(int64_t hidden)
+{
+    const XtxTail plan = xtx_tail_plan(hidden, 1);
+    return plan.splits ? (size_t)plan.splits * plan.n_tail * T2 * T2 * sizeof(float) : 0;
+}
+
+extern "C" int gq_xtx_accumulate_tail(float *hessian, float *tail_ws, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
+                                      gq_stream_t stream)
+{
+    const char *who = "gq_xtx_accumulate_tail";
+    GQ_REQUIRE(hessian && tail_ws && (x || n_tokens == 0), "%s: NULL pointer", who);
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "%s: dtype %d is neither fp16 (0) nor bf16 (1)", who, dtype);
+    GQ_REQUIRE(n_tokens >= 0 && hidden > 0 && hidden < (1 << 30), "%s: bad shape", who);
+    GQ_REQUIRE(gq_xtx_tail_workspace(hidden) > 0, "%s: hidden size %lld has no tail split (gq_xtx_tail_workspace is 0)", who, (long long)hidden);
+    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)hessian | (uintptr_t)tail_ws) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    if (n_tokens == 0) return GQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t done = 0;
+    if (n_tokens >= BK2) {
+        int rc = dtype == GQ_F16
+                     ? launch_mfma256<GQ_F16>(hessian, (const unsigned short *)x, n_tokens, hidden, 1, 1, s, done, 1, 0, tail_ws)
+                     : launch_mfma256<GQ_BF16>(hessian, (const unsigned short *)x, n_tokens, hidden, 1, 1, s, done, 1, 0, tail_ws);
+        if (rc) return rc;
+    }
+    if (done < n_tokens) {   // the tokens that do not fill a k-step: generic kernel, straight into H
+        const int nt = (int)gq_cdiv(hidden, 64);
+        const int n_blocks = nt * (nt + 1) / 2;
+        if (dtype == GQ_F16)
+            hipLaunchKernelGGL(xtx_generic_kernel<GQ_F16>, dim3(n_blocks), dim3(256), 0, s, hessian, (const unsigned short *)x, (int)hidden, done,
+                               n_tokens, nt, 1, 1);
+        else
+            hipLaunchKernelGGL(xtx_generic_kernel<GQ_BF16>, dim3(n_blocks), dim3(256), 0, s, hessian, (const unsigned short *)x, (int)hidden, done,
+                               n_tokens, nt, 1, 1);
+        GQ_LAUNCH_CHECK();
+    }
+    return GQ_OK;
+}
+
+extern "C" int gq_xtx_fold_tail(float *hessian, float *tail_ws, int64_t hidden, gq_stream_t stream)
+{
+    GQ_REQUIRE(hessian && tail_ws && hidden > 0, "gq_xtx_fold_tail: bad arguments");
+    const XtxTail plan = xtx_tail_plan(hidden, 1);
+    GQ_REQUIRE(plan.splits > 0, "gq_xtx_fold_tail: hidden size %lld has no tail split", (long long)hidden);
+    const int nt = (int)(hidden / T2);
+    const uint32_t table = xtx_order(nt, xtx_super_tile(6), 1);
+    hipLaunchKernelGGL(xtx_fold_tail_kernel, dim3(plan.n_tail), dim3(256), 0, (hipStream_t)stream, hessian, tail_ws, (int)hidden, table,
+                       plan.n_full, plan.n_tail, plan.splits, 1);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
 
 extern "C" int gq_xtx_fold(float *parts, int n_parts, int64_t part_stride, int64_t hidden, gq_stream_t stream)
 {

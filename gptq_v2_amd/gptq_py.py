@@ -38,6 +38,11 @@ class HessianHook:
         # first adds the other parts into it.
         self._parts: Optional[torch.Tensor] = None
         self._parts_dirty = False
+        # With many tiles that do not fill whole rounds of one workgroup per CU (C = 11008: 3 rounds + 178 tiles) the
+        # tiles of the last round are cut into token runs that accumulate into tile-sized buffers
+        # (ops.xtx_accumulate_tail); reading `hessian` first folds them in.
+        self._tail: Optional[torch.Tensor] = None
+        self._tail_dirty = False
         self._overlap = bool(overlap_batches)
         self._lanes = 1          # accumulators that take turns (2 with overlap_batches where it pays)
         self._per_lane = 1       # partial Hessians of one accumulator (the token split)
@@ -61,6 +66,9 @@ class HessianHook:
                 main.wait_stream(st)
             ops.xtx_fold(self._parts)
             self._parts_dirty = False
+        if self._tail_dirty:
+            ops.xtx_fold_tail(self._hessian, self._tail)
+            self._tail_dirty = False
         return self._hessian
 
     @hessian.setter
@@ -68,6 +76,8 @@ class HessianHook:
         self._hessian = value
         self._parts = None
         self._parts_dirty = False
+        self._tail = None
+        self._tail_dirty = False
         self._lanes = self._per_lane = 1
 
     @torch.no_grad()
@@ -108,6 +118,9 @@ class HessianHook:
                 self._hessian = self._parts[0]
             else:
                 self._hessian = torch.zeros(d, d, dtype=torch.float32, device=inp.device)
+                tail_bytes = ops.xtx_tail_workspace(d) if use_kernel and inp.is_cuda and x.shape[0] >= 8192 else 0
+                if tail_bytes:
+                    self._tail = torch.zeros(tail_bytes // 4, dtype=torch.float32, device=inp.device)
         if not use_kernel:
             ops.xtx_accumulate_f32(self.hessian, x.to(dtype=torch.float32).contiguous())
             return
@@ -135,6 +148,9 @@ class HessianHook:
         elif self._parts is not None:
             ops.xtx_accumulate_split(self._parts, x, save_lower_only=False, compute_lower_only=True)
             self._parts_dirty = True
+        elif self._tail is not None:
+            ops.xtx_accumulate_tail(self._hessian, self._tail, x)
+            self._tail_dirty = True
         else:
             ops.xtx_accumulate(self._hessian, x, save_lower_only=False, compute_lower_only=True)
 

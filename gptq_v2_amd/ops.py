@@ -99,6 +99,44 @@ def xtx_fold(parts: torch.Tensor) -> None:
     _lib.check(rc, "gq_xtx_fold")
 
 
+def xtx_tail_workspace(hidden: int) -> int:
+    """Bytes of the tail buffers ``xtx_accumulate_tail`` needs for this hidden size (0: the size has no tail split)."""
+    return int(_lib.load().gq_xtx_tail_workspace(int(hidden)))
+
+
+def xtx_accumulate_tail(hessian: torch.Tensor, tail_ws: torch.Tensor, x: torch.Tensor) -> None:
+    """hessian (C, C) fp32 += x^T x with the tiles of the partly filled last round summed in ``tail_ws`` (fp32,
+    ``xtx_tail_workspace(C)`` bytes, zeroed by the caller once); ``xtx_fold_tail`` completes H."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(tail_ws, "tail_ws", torch.float32, 1)
+    _check(x, "x", None, 2)
+    code = _dtype_code(x)
+    n, c = x.shape
+    if hessian.shape != (c, c):
+        raise ValueError(f"hessian is {tuple(hessian.shape)}, x has {c} columns")
+    if x.device != hessian.device or tail_ws.device != hessian.device:
+        raise ValueError("hessian, tail_ws and x are on different devices")
+    need = xtx_tail_workspace(c)
+    if need == 0 or tail_ws.numel() * 4 < need:
+        raise ValueError(f"tail_ws holds {tail_ws.numel() * 4} bytes, hidden size {c} needs {need} (0: no tail split)")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_xtx_accumulate_tail(_p(hessian), _p(tail_ws), _p(x), code, n, c, _stream(x))
+    _lib.check(rc, "gq_xtx_accumulate_tail")
+
+
+def xtx_fold_tail(hessian: torch.Tensor, tail_ws: torch.Tensor) -> None:
+    """Adds the tail buffers into ``hessian`` (index order), clears them, writes the tail tiles' mirror images."""
+    _check(hessian, "hessian", torch.float32, 2)
+    _check(tail_ws, "tail_ws", torch.float32, 1)
+    c = hessian.shape[0]
+    need = xtx_tail_workspace(c)
+    if need == 0 or tail_ws.numel() * 4 < need:
+        raise ValueError(f"tail_ws holds {tail_ws.numel() * 4} bytes, hidden size {c} needs {need} (0: no tail split)")
+    with torch.cuda.device(hessian.device):
+        rc = _lib.load().gq_xtx_fold_tail(_p(hessian), _p(tail_ws), c, _stream(hessian))
+    _lib.check(rc, "gq_xtx_fold_tail")
+
+
 def xtx_accumulate_f32(hessian: torch.Tensor, x: torch.Tensor) -> None:
     """hessian (C, C) fp32 += x^T x for x (N, C) fp32 (the reference's add_batch(use_kernel=False)
     arithmetic, gptq_py.py:31-33).  N is padded to a multiple of 4 with zero rows."""

@@ -77,6 +77,19 @@ int gq_xtx_accumulate_split(float *parts, int n_parts, int64_t part_stride, cons
                             int64_t hidden, int save_lower_only, int compute_lower_only, gq_stream_t stream);
 int gq_xtx_fold(float *parts, int n_parts, int64_t part_stride, int64_t hidden, gq_stream_t stream);
 
+/* The same accumulation (lower tiles computed, mirror images written) for hidden sizes whose tiles do not fill
+ * whole rounds of one workgroup per CU (hidden = 11008: 946 lower tiles = 3 rounds of 256 + 178): the tiles of the
+ * last, partly filled round are cut into token runs and summed in tile-sized buffers in tail_ws, everything else goes
+ * straight into H.  gq_xtx_tail_workspace(hidden) is the size of tail_ws in bytes, 0 when the hidden size has no
+ * such tail (then use gq_xtx_accumulate); the caller zeroes tail_ws once, may call gq_xtx_accumulate_tail any number
+ * of times, and calls gq_xtx_fold_tail before reading H: it adds the buffers into H in index order, clears them
+ * and writes the tail tiles' mirror images.  Until then the tail tiles of H are stale.
+ * ref: gptq_triton/accumulate_hessian.py:134-149 (same contract once folded). */
+size_t gq_xtx_tail_workspace(int64_t hidden);
+int gq_xtx_accumulate_tail(float *hessian, float *tail_ws, const void *x, int dtype, int64_t n_tokens, int64_t hidden,
+                           gq_stream_t stream);
+int gq_xtx_fold_tail(float *hessian, float *tail_ws, int64_t hidden, gq_stream_t stream);
+
 /* The same accumulation for fp32 activations X[n_tokens][hidden]: full product on the fp32 matrix
  * core, every element one k-ascending chain of fused multiply-adds (exactly symmetric result).
  * n_tokens and hidden must be multiples of 4 (zero rows may be appended to X).

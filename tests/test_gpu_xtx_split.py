@@ -114,3 +114,71 @@ def test_hook_with_two_accumulators_matches_one(amd, gpu):
     short = amd.HessianHook(overlap_batches=True)
     short.add_batch(torch.zeros(2048, c, dtype=torch.float16, device=gpu))
     assert short._lanes == 1
+
+
+def test_tail_workspace(amd):
+    ws = amd.ops.xtx_tail_workspace
+    assert ws(11008) == 4 * 178 * 256 * 256 * 4   # 946 lower tiles = 3 rounds of 256 + 178, those in 4 token runs
+    assert ws(4096) == 0                          # 136 tiles: the uniform token split's case
+    assert ws(8192) == 7 * 16 * 256 * 256 * 4     # 528 tiles = 2 rounds + 16: 7 runs, under half a round of short workgroups
+    assert ws(9728) == 0                          # 741 tiles = 2 rounds + 229: the last round is nearly full already
+    assert ws(11000) == 0                         # no 256-tiles
+    assert ws(5888) > 0                           # 276 tiles = 1 round + 20
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("c,ns", [(5888, (8192, 4096 + 19, 64)), (11008, (16384, 2048 + 5))])
+def test_tail_accumulate_equals_single(amd, gpu, dtype, c, ns):
+    """Calls of several lengths (one too short to cut, one that does not fill a k-step) into H + tail buffers, folded:
+    the tiles of the whole rounds bit for bit those of the plain accumulation, the tail's equal up to the order of the
+    fp32 sums, H exactly symmetric, buffers cleared, the same calls the same bits."""
+    gen = torch.Generator(device=gpu).manual_seed(c)
+    scale = 1 + 3 * torch.arange(c, device=gpu) / c
+    xs = [(torch.randn(n, c, generator=gen, device=gpu) * scale).to(dtype) for n in ns]
+    want = torch.zeros(c, c, device=gpu)
+    for x in xs:
+        amd.ops.xtx_accumulate(want, x)
+
+    def run():
+        h = torch.zeros(c, c, device=gpu)
+        ws = torch.zeros(amd.ops.xtx_tail_workspace(c) // 4, device=gpu)
+        for x in xs:
+            amd.ops.xtx_accumulate_tail(h, ws, x)
+        assert float(ws.abs().max()) > 0
+        stale = int((h != want).sum())
+        amd.ops.xtx_fold_tail(h, ws)
+        assert float(ws.abs().max()) == 0.0
+        return h, stale
+
+    h, stale = run()
+    assert stale > 0                                  # some tiles really went through the buffers
+    assert torch.equal(h, h.t())
+    differ = h != want
+    nt = c // 256
+    tiles_off = int(differ.view(nt, 256, nt, 256).any(dim=3).any(dim=1).sum())
+    n_tail = amd.ops.xtx_tail_workspace(c) // (256 * 256 * 4)   # runs x tiles
+    print(f"C={c}: {tiles_off} of {nt * nt} tiles differ in some bit from the plain accumulation")
+    assert 0 < tiles_off <= 2 * n_tail
+    assert float((h - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert torch.equal(run()[0], h)
+
+
+def test_hook_uses_the_tail_split_at_11008(amd, gpu):
+    c = 11008
+    gen = torch.Generator(device=gpu).manual_seed(9)
+    hook = amd.HessianHook()
+    plain = torch.zeros(c, c, device=gpu)
+    for _ in range(2):
+        x = torch.randn(4, 2048, c, generator=gen, device=gpu).half()
+        hook.add_batch(x)
+        amd.ops.xtx_accumulate(plain, x.flatten(end_dim=-2))
+    assert hook._tail is not None and hook._tail_dirty
+    h = hook.hessian
+    assert not hook._tail_dirty and torch.equal(h, h.t())
+    assert float((h - plain).abs().max()) <= 1e-5 * float(plain.abs().max())
+    # one sequence per call: not worth the buffers
+    single = amd.HessianHook()
+    single.add_batch(x[0])
+    assert single._tail is None
+    hook.hessian = torch.ones(1, device=gpu)
+    assert hook._tail is None
