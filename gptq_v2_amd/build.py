@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libgptq_amd.so")
-SOURCES = ["gq_core.hip", "xtx.hip", "hessian.hip", "sgemm.hip", "quantize.hip", "pack.hip", "w4a16.hip", "wq_stream.hip", "gemm_nt.hip"]
+SOURCES = ["gq_core.hip", "xtx.hip", "hessian.hip", "sgemm.hip", "quantize.hip", "pack.hip", "w4a16.hip", "wq_stream.hip", "gemm_nt.hip", "elementwise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
 

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from . import dist as gd
+from . import ops
 from .gptq_py import HessianHook, gptq_quant_set
 from .quant import HipLinear, QuantLinear, reconstruct_weight
 
@@ -78,6 +79,7 @@ class _HostCopier:
             shared = os.environ.get("GQ_COPIER_STREAM") == "side"
             self._stream = _side_streams(device)[-1] if shared else torch.cuda.Stream(device)
         self._futures: Dict[str, object] = {}
+        self._chunks = None   # two pinned staging chunks, made by the copying thread on first use
 
     def submit(self, key: str, obj) -> None:
         if self._stream is None:
@@ -87,10 +89,54 @@ class _HostCopier:
         ready.record()   # on the caller's stream: everything enqueued so far produces `obj`
         self._futures[key] = self._pool.submit(self._run, obj, ready)
 
+    # Device -> host through two pinned chunks: a copy into pageable memory goes through the runtime's own staging at
+    # about 4 GB/s and occupies the GPU with a copy kernel per piece (traced: 38 ms of copy kernels per Llama-2-7B block,
+    # beside the kernels of the next set); into pinned memory it is one DMA at the link's rate.  The finished chunk is
+    # copied on to the pageable result by this thread while the next one is in flight.
+    _CHUNK = 32 << 20
+
+    def _pinned(self):
+        if self._chunks is None:
+            try:
+                self._chunks = [torch.empty(self._CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            except RuntimeError:
+                self._chunks = []   # no pinned memory to be had: plain copies
+        return self._chunks
+
+    def _tensor_to_host(self, t: torch.Tensor) -> torch.Tensor:
+        n = t.numel() * t.element_size()
+        if t.device.type != "cuda" or n < (1 << 20) or not self._pinned():
+            return t.to("cpu")
+        src = t.contiguous().view(-1).view(torch.uint8)
+        out = torch.empty(t.shape, dtype=t.dtype)
+        dst = out.view(-1).view(torch.uint8)
+        pieces = [(o, min(n, o + self._CHUNK)) for o in range(0, n, self._CHUNK)]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        for k in range(len(pieces) + 1):
+            if k < len(pieces):
+                b, e = pieces[k]
+                # (chunk k % 2 last held piece k - 2, which turn k - 1 drained below)
+                self._chunks[k % 2][:e - b].copy_(src[b:e], non_blocking=True)
+                done[k % 2].record()
+            if k >= 1:
+                pb, pe = pieces[k - 1]
+                done[(k - 1) % 2].synchronize()
+                dst[pb:pe].copy_(self._chunks[(k - 1) % 2][:pe - pb])
+        return out
+
+    def _to_host(self, obj):
+        if isinstance(obj, torch.Tensor):
+            return self._tensor_to_host(obj)
+        if isinstance(obj, dict):
+            return {k: self._to_host(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self._to_host(v) for v in obj)
+        return obj
+
     def _run(self, obj, ready):
         with torch.cuda.stream(self._stream):
             self._stream.wait_event(ready)
-            return _to_device(obj, torch.device("cpu"))   # synchronous: `obj` stays referenced until it is done
+            return self._to_host(obj)   # synchronous: `obj` stays referenced until it is done
 
     def collect(self) -> Dict[str, dict]:
         return {key: (fut.result() if hasattr(fut, "result") else fut) for key, fut in self._futures.items()}
@@ -119,10 +165,33 @@ def _is_llama_layout(block: nn.Module, sets) -> bool:
         return False
     try:
         mods = [_submodule(block, nm) for names in LLAMA_SETS for nm in names]
-        ok = callable(block.mlp.act_fn) and isinstance(block.post_attention_layernorm, nn.Module)
+        ok = (callable(block.mlp.act_fn) and isinstance(block.post_attention_layernorm, nn.Module)
+              and isinstance(block.input_layernorm, nn.Module))
     except AttributeError:
         return False
     return ok and type(block).__name__ == "LlamaDecoderLayer" and all(getattr(m, "bias", None) is None for m in mods)
+
+
+_HALF = (torch.float16, torch.bfloat16)
+
+
+def _rms_norm(mod: nn.Module, x: torch.Tensor, fused: bool) -> torch.Tensor:
+    """``mod(x)``; for the Llama RMS norm on 16-bit device activations in one pass (ops.rmsnorm keeps the module's
+    roundings: seven framework operators and 4.6 GB of traffic per 268 MB batch otherwise)."""
+    w = getattr(mod, "weight", None)
+    if (fused and type(mod).__name__ == "LlamaRMSNorm" and hasattr(mod, "variance_epsilon") and isinstance(w, torch.Tensor)
+            and x.is_cuda and x.dtype in _HALF and w.dtype == x.dtype and w.device == x.device and x.is_contiguous()
+            and x.shape[-1] % 8 == 0 and w.shape == (x.shape[-1],)):
+        return ops.rmsnorm(x, w.data.contiguous(), float(mod.variance_epsilon))
+    return mod(x)
+
+
+def _act_mul(act_fn, g: torch.Tensor, u: torch.Tensor, fused: bool) -> torch.Tensor:
+    """``act_fn(g) * u``; for SiLU on 16-bit device activations in one pass, into g's memory."""
+    if (fused and type(act_fn).__name__ in ("SiLU", "SiLUActivation") and g.is_cuda and g.dtype in _HALF and u.dtype == g.dtype
+            and g.shape == u.shape and g.is_contiguous() and u.is_contiguous() and g.numel() % 8 == 0):
+        return ops.silu_mul(g, u, out=g)
+    return act_fn(g) * u
 
 
 @torch.no_grad()
@@ -173,6 +242,7 @@ def quantize_llama(
         scale_bit_width: Optional[int] = None,
         staged: Optional[bool] = None,
         offload: bool = False,
+        fused_elementwise: bool = True,
 ) -> Dict[str, Dict[str, dict]]:
     """Quantise every decoder block of ``model`` in place (llama.py:64-204).
 
@@ -193,7 +263,10 @@ def quantize_llama(
     has that layout; False: always re-run the block up to each hooked Linear; True is only valid
     with the default ``sets``).  ``offload``: move each finished block back to the CPU, as the
     reference does (llama.py:194-196); without it the whole quantised model stays on ``device``
-    (about 2 bytes per weight: 13 GB for Llama-2-7B, 138 GB for 70B, inside one MI355X's 288 GB)."""
+    (about 2 bytes per weight: 13 GB for Llama-2-7B, 138 GB for 70B, inside one MI355X's 288 GB).
+    ``fused_elementwise``: the staged walk runs the block's two RMS norms and ``act(gate) * up`` as one-pass
+    kernels with the modules' own roundings (only the order in which a row's squares are summed differs, so an
+    activation can differ from the module's in its last bit); False runs the modules themselves."""
     if staged and [list(s_) for s_ in sets] != LLAMA_SETS:
         raise ValueError("staged=True walks the Llama block layout and needs the default `sets`")
     rank, world = gd.world()
@@ -295,72 +368,83 @@ def quantize_llama(
             setattr(parent, name.rsplit(".", 1)[-1], layer)
 
     def run_until(block, name, hook, keep=None, entry=None):
-        """forward of every batch up to the input of sub-module `name`: into the Hessian, and into
-        `keep` (a preallocated tensor) if given.  `entry` = (sub-module, its cached inputs): start there
-        instead of at the block's first layer."""
-        pos = [0]
+        """forward of every batch up to the input of sub-module `name`: into the Hessian, and appended to the list
+        `keep` if given (the tensor the module was about to receive, not a copy: nothing writes it afterwards).
+        `entry` = (sub-module, its inputs, one tensor per batch): start there instead of at the block's first layer."""
 
         def feed(_mod, args):
             x = args[0]
             hook.add_batch(x)
             if keep is not None:
-                keep[pos[0]:pos[0] + len(x)] = x
-            pos[0] += len(x)
+                keep.append(x)
             raise _Stop()
 
         handle = _submodule(block, name).register_forward_pre_hook(feed)
         try:
-            for b, e in batches:
+            for i in range(len(batches)):
                 try:
                     if entry is None:
-                        block(inps[b:e], **inp_kwargs)
+                        block(xs[i], **inp_kwargs)
                     else:
-                        entry[0](hidden_states=entry[1][b:e], **inp_kwargs)
+                        entry[0](hidden_states=entry[1][i], **inp_kwargs)
                 except _Stop:
                     pass
         finally:
             handle.remove()
 
+    # Activations are kept as one tensor per batch, each the very tensor its producer returned: a preallocated
+    # (sequences, tokens, features) buffer filled slice by slice costs a device copy of every activation at every stage
+    # (traced on Llama-2-7B dimensions: 47 ms of 250 ms per block in copy kernels).
+    xs = [inps[b:e] for b, e in batches]
+    del inps
     try:
         for gi, block in enumerate(model.model.layers):
             t0 = time.time()
             block.to(device)
-            nxt = torch.empty_like(inps)
+            nxt = [None] * len(batches)
             if _is_llama_layout(block, sets) if staged is None else staged:
                 # stage 1: q, k, v see the first norm's output.  (The hooks alternate between two accumulators where a
                 # call is a short launch; nothing below writes an input again before its set is quantised.)
                 hook = HessianHook(overlap_batches=True)
-                normed = torch.empty_like(inps)
-                run_until(block, sets[0][0], hook, keep=normed)
+                normed = []
+                if fused_elementwise:
+                    for i in range(len(batches)):
+                        normed.append(_rms_norm(block.input_layernorm, xs[i], True))
+                        hook.add_batch(normed[i])
+                else:
+                    run_until(block, sets[0][0], hook, keep=normed)
                 quantise_set(gi, block, sets[0], hook)
                 # stage 2: attention once, on the first norm's output as stage 1 saw it; its output is o_proj's input
                 hook = HessianHook(overlap_batches=True)
-                attn = torch.empty(n, inps.shape[1], _submodule(block, sets[1][0]).in_features, dtype=dtype, device=device)
+                attn = []
                 run_until(block, sets[1][0], hook, keep=attn, entry=(block.self_attn, normed))
                 del normed
                 quantise_set(gi, block, sets[1], hook)
                 # stage 3: h = x + o_proj(attn), z = norm2(h) feeds gate and up
                 hook = HessianHook(overlap_batches=True)
                 o_proj = _submodule(block, sets[1][0])
-                h, z = torch.empty_like(inps), torch.empty_like(inps)
-                for b, e in batches:
-                    h[b:e] = inps[b:e] + o_proj(attn[b:e])
-                    z[b:e] = block.post_attention_layernorm(h[b:e])
-                    hook.add_batch(z[b:e])
+                h, z = [], []
+                for i in range(len(batches)):
+                    h.append(xs[i] + o_proj(attn[i]))
+                    attn[i] = xs[i] = None
+                    z.append(_rms_norm(block.post_attention_layernorm, h[i], fused_elementwise))
+                    hook.add_batch(z[i])
                 del attn
                 quantise_set(gi, block, sets[2], hook)
                 # stage 4: a = act(gate(z)) * up(z) feeds down
                 hook = HessianHook(overlap_batches=True)
                 gate, up = _submodule(block, sets[2][0]), _submodule(block, sets[2][1])
-                act = torch.empty(n, inps.shape[1], gate.out_features, dtype=dtype, device=device)
-                for b, e in batches:
-                    act[b:e] = block.mlp.act_fn(gate(z[b:e])) * up(z[b:e])
-                    hook.add_batch(act[b:e])
+                act = []
+                for i in range(len(batches)):
+                    act.append(_act_mul(block.mlp.act_fn, gate(z[i]), up(z[i]), fused_elementwise))
+                    z[i] = None
+                    hook.add_batch(act[i])
                 del z
                 quantise_set(gi, block, sets[3], hook)
                 down = _submodule(block, sets[3][0])
-                for b, e in batches:
-                    nxt[b:e] = h[b:e] + down(act[b:e])
+                for i in range(len(batches)):
+                    nxt[i] = h[i] + down(act[i])
+                    h[i] = act[i] = None
                 del h, act, hook
             else:
                 for names in sets:
@@ -368,9 +452,10 @@ def quantize_llama(
                     run_until(block, names[0], hook)
                     quantise_set(gi, block, names, hook)
                     del hook
-                for b, e in batches:
-                    nxt[b:e] = _first(block(inps[b:e], **inp_kwargs))
-            inps = nxt
+                for i in range(len(batches)):
+                    nxt[i] = _first(block(xs[i], **inp_kwargs))
+                    xs[i] = None
+            xs = nxt
             if offload:
                 block.to("cpu")
             results["seconds_per_block"].append(time.time() - t0)
@@ -393,21 +478,22 @@ def evaluate_llama(model: nn.Module, encodings: torch.Tensor, device: torch.devi
     inps, inp_kwargs = get_initial_inputs(model, encodings, device, batch_size)
     inp_kwargs = _to_device(inp_kwargs, device)
     use_cache, model.config.use_cache = model.config.use_cache, False
+    xs = [inps[bi:bi + batch_size] for bi in range(0, len(inps), batch_size)]   # one tensor per batch, never copied together
+    del inps
     for block in model.model.layers:
         block.to(device)
-        nxt = torch.empty_like(inps)
-        for bi in range(0, len(inps), batch_size):
-            nxt[bi:bi + batch_size] = _first(block(inps[bi:bi + batch_size], **inp_kwargs))
-        inps = nxt
+        for i in range(len(xs)):
+            xs[i] = _first(block(xs[i], **inp_kwargs))
     if getattr(model.model, "norm", None) is not None:
         model.model.norm.to(device)
-        for bi in range(0, len(inps), batch_size):
-            inps[bi:bi + batch_size] = model.model.norm(inps[bi:bi + batch_size])
+        for i in range(len(xs)):
+            xs[i] = model.model.norm(xs[i])
     model.lm_head.to(device)
     loss = nn.CrossEntropyLoss()
     nlls = []
-    for bi in range(0, len(inps), batch_size):
-        logits = model.lm_head(inps[bi:bi + batch_size])
+    for i, bi in enumerate(range(0, len(encodings), batch_size)):
+        logits = model.lm_head(xs[i])
+        xs[i] = None
         labels = encodings[bi:bi + batch_size, 1:].to(device)
         flat = logits[:, :-1, :].flatten(end_dim=-2)
         nll = loss(flat.float() if loss_in_fp32 else flat, labels.flatten())

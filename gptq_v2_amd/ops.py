@@ -99,6 +99,46 @@ def xtx_fold(parts: torch.Tensor) -> None:
     _lib.check(rc, "gq_xtx_fold")
 
 
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMS normalisation over the last dimension of x (fp16 / bf16) in one pass, with the roundings of the usual
+    operator chain: ``weight * (x.float() * rsqrt(mean(x.float() ** 2) + eps)).to(x.dtype)``."""
+    _check(x, "x", None, None)
+    _check(weight, "weight", x.dtype, 1)
+    code = _dtype_code(x)
+    hidden = x.shape[-1]
+    if weight.shape[0] != hidden or weight.device != x.device:
+        raise ValueError(f"weight is {tuple(weight.shape)} on {weight.device}, x has {hidden} columns on {x.device}")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _check(out, "out", x.dtype, None)
+        if out.shape != x.shape or out.device != x.device:
+            raise ValueError("out does not match x")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_rmsnorm(_p(out), _p(x), _p(weight), code, x.numel() // hidden, hidden, float(eps), _stream(x))
+    _lib.check(rc, "gq_rmsnorm")
+    return out
+
+
+def silu_mul(gate: torch.Tensor, up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu(gate) * up in one pass (fp16 / bf16), rounded as ``F.silu(gate) * up`` rounds."""
+    _check(gate, "gate", None, None)
+    _check(up, "up", gate.dtype, None)
+    code = _dtype_code(gate)
+    if up.shape != gate.shape or up.device != gate.device:
+        raise ValueError("gate and up differ in shape or device")
+    if out is None:
+        out = torch.empty_like(gate)
+    else:
+        _check(out, "out", gate.dtype, None)
+        if out.shape != gate.shape or out.device != gate.device:
+            raise ValueError("out does not match gate")
+    with torch.cuda.device(gate.device):
+        rc = _lib.load().gq_silu_mul(_p(out), _p(gate), _p(up), code, gate.numel(), _stream(gate))
+    _lib.check(rc, "gq_silu_mul")
+    return out
+
+
 def xtx_tail_workspace(hidden: int) -> int:
     """Bytes of the tail buffers ``xtx_accumulate_tail`` needs for this hidden size (0: the size has no tail split)."""
     return int(_lib.load().gq_xtx_tail_workspace(int(hidden)))

@@ -353,6 +353,17 @@ int gq_set_quant_super(int on);
 int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int64_t n, int64_t k, int dtype,
                gq_stream_t stream);
 
+/* The two bandwidth-bound operators between the GEMMs of a Llama block's staged replay, one pass each, with the
+ * roundings of the operator chains they replace (only the order of the sum of squares is the kernel's own):
+ *   gq_rmsnorm:  out = T(float(weight) * float(T(float(x) * rsqrt(mean(float(x)^2) + eps))))   per row of `hidden`
+ *   gq_silu_mul: out = T(float(T(silu(float(gate)))) * float(up))                                per element
+ * T = fp16 or bf16 (dtype); hidden and n multiples of 8, pointers 16-byte aligned; out may alias x / gate.
+ * ref: llama.py:172-190 replays the block's own modules (the model's RMS norm and MLP); these take their place
+ *      in the stage-wise replay of gptq_v2_amd.driver.quantize_llama. */
+int gq_rmsnorm(void *out, const void *x, const void *weight, int dtype, int64_t n_rows, int64_t hidden, float eps,
+               gq_stream_t stream);
+int gq_silu_mul(void *out, const void *gate, const void *up, int dtype, int64_t n, gq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
