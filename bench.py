@@ -554,6 +554,21 @@ def main():
         t_call = px.total_ms() / max(px.units, 1) * 1e-3   # per add_batch call, the final sum of the accumulators included
         tokens_call = min(args.batch, se - sb) * SEQ
         xtx_tflops = 2.0 * tokens_call * hidden * hidden / t_call / 1e12 if t_call > 0 else 0.0   # full product, as the algorithmic figure counts it
+
+        def xtx_figures(c):
+            """algorithmic (full product 2 N C^2) and executed (the lower 256 x 256 tiles the kernel computes, diagonal
+            tiles whole) TFLOP/s of the XtX calls of width c"""
+            ph = phases.get("xtx_%d" % c)
+            if ph is None or not ph.units or c % 256:
+                return None
+            t = ph.total_ms() / ph.units * 1e-3
+            nt = c // 256
+            executed = nt * (nt + 1) // 2 * 2.0 * 256 * 256 * tokens_call
+            return {"C": c, "avg_call_ms": round(t * 1e3, 4), "algorithmic_tflops": round(2.0 * tokens_call * c * c / t / 1e12, 1),
+                    "executed_tflops": round(executed / t / 1e12, 1),
+                    "executed_frac_of_f16_mfma_peak": round(executed / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                    "lower_tiles": nt * (nt + 1) // 2}
+
         # dominant kernel: the replay GEMM; algorithmic flops 2 M R C per launch and launch duration,
         # both as means over the launches of a block
         pr = phases["replay_gemm"]
@@ -595,6 +610,9 @@ def main():
                              "unit": "TFLOP/s", "frac": round(xtx_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                              "traffic": pmc_bytes(os.path.join(ROOT, "profiles", "xtx_traffic.json"), "xtx.hip"),
                              "avg_launch_ms": round(t_call * 1e3, 4),
+                             "achieved_is": "algorithmic: the full product's 2 N C^2 flops; the kernel computes the tiles on and "
+                                            "below the diagonal only, see by_width[].executed_tflops",
+                             "by_width": [f for f in (xtx_figures(c) for c in widths) if f],
                              "timing": "window of a set's add_batch calls and the final sum, divided by the calls "
                                        "(consecutive calls overlap on two streams), not one launch alone"},
         }

@@ -71,6 +71,7 @@ SIGNATURES = {
                            c_int, c_int, c_int, c_void_p]),
     "gq_wq_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "gq_set_wq_kernel": (c_int, [c_int]),
+    "gq_set_w4_tile": (c_int, [c_int]),
     "gq_set_quant_super": (c_int, [c_int]),
     "gq_xtx_split_hint": (c_int, [c_int64, c_int64, c_int]),
     "gq_xtx_accumulate_split": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),

@@ -150,7 +150,8 @@ struct DeqConstB {
     f32x2 nzs2;
 };
 
-__device__ __forceinline__ DeqConstB deq_const_bf16(const WRegs &w)
+template <class W>
+__device__ __forceinline__ DeqConstB deq_const_bf16(const W &w)
 {
     DeqConstB d;
     const float s = __uint_as_float(w.s_raw << 16);
@@ -317,7 +318,8 @@ struct DeqConst {
     f16x2 s2;
 };
 
-__device__ __forceinline__ DeqConst deq_const(const WRegs &w)
+template <class W>
+__device__ __forceinline__ DeqConst deq_const(const W &w)
 {
     DeqConst d;
     const _Float16 s = __builtin_bit_cast(_Float16, (unsigned short)w.s_raw);
@@ -328,8 +330,8 @@ __device__ __forceinline__ DeqConst deq_const(const WRegs &w)
     return d;
 }
 
-template <int DT>
-__device__ __forceinline__ auto deq_const_dt(const WRegs &w)
+template <int DT, class W>
+__device__ __forceinline__ auto deq_const_dt(const W &w)
 {
     if constexpr (DT == GQ_F16) return deq_const(w);
     else return deq_const_bf16(w);
@@ -422,7 +424,17 @@ __device__ __forceinline__ void stage_x2(const unsigned short *__restrict__ x, i
     }
 }
 
-template <int DT>
+// NB = 32-column MFMA blocks per wave: 2 is the 256 x 256 tile described above; 1 is a 256 (M) x 128 (N) tile
+// with the same x image, schedule and waves (each 128 x 32), for shapes whose 256 x 256 tiles would leave CUs
+// without a workgroup (M = 2048 against 4096 rows: 128 tiles on 256 CUs; 256 x 128 gives exactly 256).
+template <int WORDS>
+struct W2Regs {
+    unsigned q __attribute__((ext_vector_type(WORDS)));   // WORDS * 8 packed values of one W row
+    unsigned s_raw;
+    unsigned z_raw;
+};
+
+template <int DT, int NB>
 __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
                                                         const uint32_t *__restrict__ qw, const unsigned short *__restrict__ scale,
                                                         const uint8_t *__restrict__ zero, int64_t m_total, int64_t r_total,
@@ -452,7 +464,10 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         tn = within / rows;
         tm = b * band + (within - tn * rows);
     }
-    const int64_t m0 = (int64_t)tm * W2T, n0 = (int64_t)tn * W2T;
+    constexpr int TN = 128 * NB;          // tile width (rows of W)
+    constexpr int WPT = 2 * NB;           // packed words a thread expands per k-step
+    constexpr int TPR = 8 / WPT;          // threads per W row
+    const int64_t m0 = (int64_t)tm * W2T, n0 = (int64_t)tn * TN;
     const int n_ktiles = (int)(c_total / WK);
 
     const int wr = wave >> 2, wc = wave & 3;
@@ -461,19 +476,19 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     // row bases of the wave's MFMA blocks; the chunk of k-step kk is (2*kk + lh) ^ sw with
     // sw = (row >> 1) & 7 = (li >> 1) & 7 for every block (block offsets are multiples of 32 rows)
     const int sw = (li >> 1) & 7;
-    unsigned rowA[4], rowB[2], choff[4];
+    unsigned rowA[4], rowB[NB], choff[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) rowA[u] = lds_base + ((wr * 4 + u) * 32 + li) * 128;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) rowB[u] = lds_base + W2_OP_BYTES + ((wc * 2 + u) * 32 + li) * 128;
+    for (int u = 0; u < NB; ++u) rowB[u] = lds_base + W2_OP_BYTES + ((wc * NB + u) * 32 + li) * 128;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) choff[kk] = (unsigned)(((2 * kk + lh) ^ sw) << 4);
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
 
@@ -487,7 +502,8 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     // vmcnt for this wave's DMA) before the barrier that ends it, so the barrier hands the data over.
     // W registers run two steps ahead: the packed words of step k+1 are in registers when step k
     // starts (loaded during step k-1).
-    WRegs wcur, wnext{};
+    using WR = W2Regs<WPT>;
+    WR wcur, wnext{};
     W2Cursor csr;
     csr.q = reinterpret_cast<const char *>(qw + n0 * 8);
     csr.s = scale + n0;
@@ -495,16 +511,17 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     csr.rem = 0;
     unsigned voff_q, voff_g;   // this thread's row (clamped to the last one) and half inside the tile
     {
-        int64_t nl = tid >> 1;
+        int64_t nl = tid / TPR;
         nl = n0 + nl < r_total ? nl : r_total - 1 - n0;   // rows past the end shadow the last row; never stored
-        voff_q = (unsigned)(nl * 32 + (tid & 1) * 16);
+        voff_q = (unsigned)(nl * 32 + (tid % TPR) * (WPT * 4));
         voff_g = (unsigned)nl;
     }
     const int64_t kstep_bytes = r_total * 32;
-    auto load_w2 = [&](WRegs &w) {
+    auto load_w2 = [&](WR &w) {
         // Issued as asm so that hipcc neither widens the 16- and 8-bit results right behind the loads
         // (which drags a vmcnt(0) to the next barrier) nor counts them: the consumer waits by hand.
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.q) : "v"(csr.q + voff_q) : "memory");
+        if constexpr (WPT == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.q) : "v"(csr.q + voff_q) : "memory");
+        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w.q) : "v"(csr.q + voff_q) : "memory");
         asm volatile("global_load_ushort %0, %1, off" : "=v"(w.s_raw) : "v"(csr.s + voff_g) : "memory");
         asm volatile("global_load_ubyte %0, %1, off" : "=v"(w.z_raw) : "v"(csr.z + voff_g) : "memory");
         csr.q += kstep_bytes;
@@ -517,11 +534,11 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     };
     unsigned magic0 = 0x64006400u, magic1 = 0x54005400u;
     asm volatile("" : "+v"(magic0), "+v"(magic1));   // keep them in VGPRs (operands of v_and_or_b32)
-    const int wrow = tid >> 1, whalf = tid & 1;
+    const int wrow = tid / TPR, wpart = tid % TPR;
     using DQ = std::conditional_t<DT == GQ_F16, DeqConst, DeqConstB>;
-    auto store_part = [&](const WRegs &w, const DQ &d, int wi, char *lds_b) {
+    auto store_part = [&](const WR &w, const DQ &d, int wi, char *lds_b) {
         const u32x4 out = expand_word(w.q[wi], d, magic0, magic1);
-        const int chunk = (whalf * 4 + wi) ^ ((wrow >> 1) & 7);
+        const int chunk = (wpart * WPT + wi) ^ ((wrow >> 1) & 7);
         *reinterpret_cast<u32x4 *>(lds_b + wrow * 128 + chunk * 16) = out;
     };
     const bool late = wave >= 4;   // wave-uniform (readfirstlane above)
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     {
         const DQ d = deq_const_dt<DT>(wcur);
 #pragma unroll
-        for (int wi = 0; wi < 4; ++wi) store_part(wcur, d, wi, smem + W2_OP_BYTES);
+        for (int wi = 0; wi < WPT; ++wi) store_part(wcur, d, wi, smem + W2_OP_BYTES);
     }
     if (n_ktiles > 1) load_w2(wcur);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wcur.q), "+v"(wcur.s_raw), "+v"(wcur.z_raw)::"memory");
@@ -543,12 +560,12 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
 #ifdef GQ_W4_TRACE
     unsigned long long ts[13] = {};
 #endif
-    u32x4 fa[2][4], fb[2][2];
+    u32x4 fa[2][4], fb[2][NB];
     auto read_frags = [&](int slot, unsigned sb, int kk) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) lds_read_b128<0>(fa[slot][u], rowA[u] + sb + choff[kk]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) lds_read_b128<0>(fb[slot][u], rowB[u] + sb + choff[kk]);
+        for (int u = 0; u < NB; ++u) lds_read_b128<0>(fb[slot][u], rowB[u] + sb + choff[kk]);
     };
     // 8 MFMAs of one 16-deep k-chunk; `between(i)` runs after the MFMAs 1 and 5 of the chunk (one
     // global load per four MFMAs keeps the address unit far from saturation while the pipe is busy)
@@ -556,14 +573,14 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 if constexpr (DT == GQ_F16)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[slot][a]),
                                                                        __builtin_bit_cast(f16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
                 else
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[slot][a]),
                                                                         __builtin_bit_cast(bf16x8, fb[slot][b]), acc[a][b], 0, 0, 0);
-                if (b == 1 && (a == 0 || a == 2)) {
+                if (b == NB - 1 && (a == 0 || a == 2)) {
                     __builtin_amdgcn_sched_barrier(0);
                     between(a >> 1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
     //   waves 0..3:  M1(k): [4 DMA step k+1 -> if k > 0] 3 W   | M2(k) end: vmcnt(0)
     //   waves 4..7:  M1(k): 3 W | M2(k): 4 DMA, then vmcnt(4) for the W words | R2(k+1) end: vmcnt(3)
     //                (the 3 W loads of M1(k+1) are younger than the DMA)
-    auto body = [&](auto more_c, auto more2_c, auto first_c, int kt, WRegs &wuse, WRegs &wload) {
+    auto body = [&](auto more_c, auto more2_c, auto first_c, int kt, WR &wuse, WR &wload) {
         constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;   // step 0: its successor's x tile was staged in the prologue
         const unsigned sb = (unsigned)(kt & 1) * W2_STAGE_BYTES;
@@ -614,8 +631,8 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         DQ dq;
         if constexpr (MORE) {
             dq = deq_const_dt<DT>(wuse);
-            store_part(wuse, dq, 0, nb);
-            store_part(wuse, dq, 1, nb);
+#pragma unroll
+            for (int wi = 0; wi < WPT / 2; ++wi) store_part(wuse, dq, wi, nb);
         }
         GQ_TR(11);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -652,8 +669,8 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
         read_frags(1, sb, 3);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) {
-            store_part(wuse, dq, 2, nb);
-            store_part(wuse, dq, 3, nb);
+#pragma unroll
+            for (int wi = WPT / 2; wi < WPT; ++wi) store_part(wuse, dq, wi, nb);
         }
         // waves 4..7: their half of the next x tile (DMA from the previous M2; from the prologue in
         // step 0) must have landed before this barrier; the 3 younger W loads of M1 may stay in flight
@@ -730,11 +747,11 @@ __global__ __launch_bounds__(512) void w4a16_256_kernel(unsigned short *__restri
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = m0 + (wr * 4 + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int64_t col = n0 + (wc * 2 + b) * 32 + li;
+                const int64_t col = n0 + (wc * NB + b) * 32 + li;
                 if (row < m_total && col < r_total) {
                     if constexpr (DT == GQ_F16) y[row * r_total + col] = __builtin_bit_cast(unsigned short, (_Float16)acc[a][b][e]);
                     else y[row * r_total + col] = __builtin_bit_cast(unsigned short, (__bf16)acc[a][b][e]);
@@ -762,6 +779,8 @@ extern "C" int gq_debug_w4_trace(unsigned long long *buf)
 
 namespace {
 
+std::atomic<int> g_w4_tile{-1};   // -1: not set yet (GQ_W4_TILE decides, else automatic)
+
 int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const void *scale, const uint8_t *qzero, int64_t m,
                  int64_t r, int64_t c, int group_size, int dtype, gq_stream_t stream, const char *who)
 {
@@ -773,14 +792,40 @@ int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const v
                "%s: group size %d must be a multiple of 32 dividing in_features", who, group_size);
     GQ_REQUIRE((((uintptr_t)x | (uintptr_t)qweight_packed | (uintptr_t)y) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
     if (m == 0) return GQ_OK;
-    static const int forced = [] {   // experiments: GQ_W4_VARIANT=128 / 256 forces a tile size
-        const char *e = getenv("GQ_W4_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
-    // 256-tiles unless they would occupy at most half of the chip's 256 CUs: four times as many
-    // 128-tiles then finish sooner (measured at M = 2048: 717 against 642 TFLOP/s for 4096 x 4096).
-    const bool few_tiles = gq_cdiv(m, W2T) * gq_cdiv(r, W2T) <= 128;
-    if (m >= W2T && r >= W2T && group_size % WK == 0 && forced != 128 && (!few_tiles || forced == 256)) {
+    // Tile shape: gq_set_w4_tile / GQ_W4_TILE force one (128 = 128 x 128, 256 = 256 x 256, 384 = 256 x 128) where the
+    // shape allows it; automatic otherwise:
+    //  * 256 x 256 tiles unless they would occupy at most half of the chip's 256 CUs: four times as many 128 x 128
+    //    tiles then finish sooner (measured at M = 2048: 717 against 642 TFLOP/s for 4096 x 4096);
+    //  * 256 (M) x 128 tiles where they need less time in rounds of one workgroup per CU.  Measured (fp16, K = 4096): a
+    //    full round of theirs takes 0.62 of a 256 x 256 round (M = 16384: 869 against 1083 TFLOP/s), and at M = 2048
+    //      4096 rows   (128 wide tiles, half a round | 256 narrow, one round): 97 us (the 128 x 128 kernel) -> 86 us
+    //      4096 rows, K = 11008:                                               235 us -> 218 us
+    //      11008 rows  (344 wide = 2 rounds | 688 narrow = 3 rounds):          225 us -> 257 us: stays wide
+    //    so a narrow round is costed at 0.7 of a wide one (3 x 0.7 > 2); with at most 128 narrow tiles the 128 x 128
+    //    kernel still has one workgroup per CU or fewer and its smaller tiles are done sooner.
+    int forced = g_w4_tile.load();
+    if (forced < 0) {
+        const char *e = getenv("GQ_W4_TILE");
+        forced = e ? atoi(e) : 0;
+        int expect = -1;
+        g_w4_tile.compare_exchange_strong(expect, forced);
+    }
+    const int64_t t_wide = gq_cdiv(m, W2T) * gq_cdiv(r, W2T), t_narrow = gq_cdiv(m, W2T) * gq_cdiv(r, 128);
+    const bool few_tiles = t_wide <= 128;
+    const bool can256 = m >= W2T && group_size % WK == 0;
+    const bool narrow = forced ? forced == 384 : t_narrow > 128 && (double)gq_cdiv(t_narrow, 256) * 0.7 < (double)gq_cdiv(t_wide, 256);
+    if (can256 && r >= 128 && narrow) {
+        const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, 128);
+        const int n_blocks = tiles_m * tiles_n;
+        auto kern1 = dtype == GQ_F16 ? w4a16_256_kernel<GQ_F16, 1> : w4a16_256_kernel<GQ_BF16, 1>;
+        GQ_HIP(hipFuncSetAttribute((const void *)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+        hipLaunchKernelGGL(kern1, dim3(n_blocks), dim3(512), W2_LDS, (hipStream_t)stream, (unsigned short *)y,
+                           (const unsigned short *)x, qweight_packed, (const unsigned short *)scale, qzero, m, r, c,
+                           group_size, tiles_n, n_blocks, 2);
+        GQ_LAUNCH_CHECK();
+        return GQ_OK;
+    }
+    if (can256 && r >= W2T && forced != 128 && (!few_tiles || forced == 256)) {
         const int tiles_m = (int)gq_cdiv(m, W2T), tiles_n = (int)gq_cdiv(r, W2T);
         const int n_blocks = tiles_m * tiles_n;
         static const int band_env = [] {
@@ -788,7 +833,7 @@ int w4a16_launch(void *y, const void *x, const uint32_t *qweight_packed, const v
             return e ? atoi(e) : 0;
         }();
         const int band = band_env > 0 ? band_env : 2;   // memory-side reads of the 11008 x 4096 shape: -32 % against 1; run time unchanged
-        auto kern2 = dtype == GQ_F16 ? w4a16_256_kernel<GQ_F16> : w4a16_256_kernel<GQ_BF16>;
+        auto kern2 = dtype == GQ_F16 ? w4a16_256_kernel<GQ_F16, 2> : w4a16_256_kernel<GQ_BF16, 2>;
         GQ_HIP(hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
         hipLaunchKernelGGL(kern2, dim3(n_blocks), dim3(512), W2_LDS, (hipStream_t)stream, (unsigned short *)y,
                            (const unsigned short *)x, qweight_packed, (const unsigned short *)scale, qzero, m, r, c,
@@ -814,6 +859,14 @@ int gq_wq_stream_launch(void *y, const void *x, const uint32_t *qweight_packed, 
 
 namespace {
 std::atomic<int> g_wq_variant{-1};   // -1: not set yet (GQ_WQ_KERNEL=stream / split decides, else automatic)
+}
+
+extern "C" int gq_set_w4_tile(int tile)
+{
+    GQ_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384,
+               "gq_set_w4_tile: 0 (automatic), 128 (128 x 128), 256 (256 x 256) or 384 (256 x 128), got %d", tile);
+    const int before = g_w4_tile.exchange(tile);
+    return before < 0 ? 0 : before;
 }
 
 extern "C" int gq_set_wq_kernel(int variant)

@@ -335,6 +335,13 @@ int gq_wq_expand(void *w_out, const uint32_t *qweight_packed, const void *scale_
  * reference counterpart; the environment variable GQ_WQ_KERNEL=stream|split sets the initial value. */
 int gq_set_wq_kernel(int variant);
 
+/* Tile shape of the split 4-bit kernel: 0 = chosen by shape (the default), 128 = 128 x 128, 256 = 256 x 256,
+ * 384 = 256 tokens x 128 rows of W (for launches whose 256 x 256 tiles would leave CUs without a workgroup, e.g.
+ * 2048 tokens against 4096 rows).  A forced shape applies where the operands allow it (256-row tiles need m >= 256
+ * and groups that are multiples of 64).  Returns the previous setting, -1 on a bad argument.  A tuning knob of this
+ * library, no reference counterpart; the environment variable GQ_W4_TILE sets the initial value. */
+int gq_set_w4_tile(int tile);
+
 /* How the column loop of gq_quantize_layer / gq_quantize_layer_ex is launched for native-loop semantics
  * when every group is a multiple of 16 columns: 1 (the default) = one launch per 512 columns in which a
  * workgroup keeps its 32 rows' window in LDS and updates it between 16-column steps on the matrix core,

@@ -143,6 +143,39 @@ def test_stream_kernel_products(amd, gpu, bits, dtype, m, r, c, gsz):
         assert (y2.double() - y.double()).abs().max() <= tol * ref.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,r,c,gsz", [(2048, 4096, 4096, 128), (300, 520, 4096, 128), (4099, 4100, 320, 64), (256, 128, 64, 64),
+                                       (515, 129, 192, 64)])
+def test_split_kernel_every_tile_shape(amd, gpu, dtype, m, r, c, gsz):
+    """The split 4-bit kernel with each tile shape forced (128 x 128, 256 x 256, 256 tokens x 128 rows): the same
+    product bit for bit -- every output element is the same k-ascending sum whatever the tile -- and, with an
+    identity-like input, the dense weight itself; ragged token and row counts, one to 64 k-steps."""
+    lib = amd._lib.load()
+    meta = _random_layer(amd, gpu, r, c, gsz, 4, dtype, m + r + c)
+    w = amd.quant.reconstruct_weight(meta, dtype, gpu)
+    packed = amd.ops.pack_rows(meta["qweight"], 4, amd.ops.PACK_W4_KBLOCK)
+    scale_t, zero_t = meta["scale"].t().contiguous(), meta["qzero"].t().contiguous()
+    x = torch.randn(m, c, generator=torch.Generator().manual_seed(7)).to(dtype).to(gpu)
+    eye = torch.zeros(max(m, c), c, dtype=dtype, device=gpu)
+    eye[:c] = torch.eye(c, dtype=dtype, device=gpu)
+    kernel_before, tile_before = lib.gq_set_wq_kernel(2), lib.gq_set_w4_tile(128)
+    try:
+        ys, ws = {}, {}
+        for tile in (128, 256, 384):
+            lib.gq_set_w4_tile(tile)
+            ys[tile] = amd.ops.w4a16_gemm(x, packed, scale_t, zero_t, gsz)
+            ws[tile] = amd.ops.w4a16_gemm(eye, packed, scale_t, zero_t, gsz)
+    finally:
+        lib.gq_set_w4_tile(tile_before)
+        lib.gq_set_wq_kernel(kernel_before)
+    for tile in (128, 256, 384):
+        assert torch.equal(ws[tile][:c], w.t()), tile
+        assert float(ws[tile][c:].abs().max()) == 0.0 if m > c else True
+    assert torch.equal(ys[256], ys[384])
+    assert torch.equal(ys[128], ys[384])
+    assert lib.gq_set_w4_tile(7) == -1
+
+
 @pytest.mark.parametrize("bits", [3, 4])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_stream_kernel_every_k_step_count(amd, gpu, bits, dtype):

@@ -1,5 +1,5 @@
 """W4A16 GEMM at the QuantLinear.forward shapes of a Llama-2-7B block, seq 2048 x batch 1 / 8
-(experiment helper).  GQ_W4_VARIANT=128 / 256 forces a tile size; argv[1] = f16 (default) or bf16."""
+(experiment helper).  GQ_W4_TILE=128 / 256 / 384 forces a tile shape (384 = 256 tokens x 128 rows); argv[1] = f16 (default) or bf16."""
 import os, sys, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
