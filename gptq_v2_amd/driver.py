@@ -194,6 +194,56 @@ def _act_mul(act_fn, g: torch.Tensor, u: torch.Tensor, fused: bool) -> torch.Ten
     return act_fn(g) * u
 
 
+class _SliceOfMerged(nn.Module):
+    """Stands in for one of several Linears that read the same input: the first of them to be called runs ONE product
+    with the concatenated weight, each returns its columns of it (a view)."""
+
+    def __init__(self, shared: dict, lo: int, hi: int) -> None:
+        super().__init__()
+        self._shared, self._lo, self._hi = shared, lo, hi
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        sh = self._shared
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+        if sh.get("key") != key:
+            sh["key"], sh["y"] = key, sh["linear"](x)
+        return sh["y"][..., self._lo:self._hi]
+
+
+class _merged_linears:
+    """``with _merged_linears(parent, names):`` -- while inside, the named dense Linears of ``parent`` (same input, no
+    bias, this library's HipLinear) are replaced by slices of one product with their concatenated weight: one launch of
+    12288 rows instead of three of 4096 for q/k/v (1352 against 1152 TFLOP/s at 32768 tokens).  Every output element is
+    the same k-ascending sum either way, so the values are bit for bit those of the separate Linears.  Anything else
+    (packed layers, a bias, another module type) is left as it is."""
+
+    def __init__(self, parent: nn.Module, names: Sequence[str]) -> None:
+        self._parent, self._names, self._saved = parent, list(names), None
+
+    def __enter__(self):
+        mods = [getattr(self._parent, n, None) for n in self._names]
+        if not all(type(m) is HipLinear and m.bias is None and m.weight.is_cuda for m in mods):
+            return self
+        if len({(m.in_features, m.weight.dtype, m.weight.device) for m in mods}) != 1:
+            return self
+        shared = {"linear": HipLinear.from_weight(torch.cat([m.weight.data for m in mods], dim=0))}
+        self._saved = mods
+        lo = 0
+        for n, m in zip(self._names, mods):
+            setattr(self._parent, n, _SliceOfMerged(shared, lo, lo + m.out_features))
+            lo += m.out_features
+        self._shared = shared
+        return self
+
+    def __exit__(self, *exc):
+        if self._saved is not None:
+            for n, m in zip(self._names, self._saved):
+                setattr(self._parent, n, m)
+            self._shared.clear()
+            self._saved = None
+        return False
+
+
 @torch.no_grad()
 def get_initial_inputs(model: nn.Module, encodings: torch.Tensor, device: torch.device,
                        batch_size: int = 1) -> Tuple[torch.Tensor, dict]:
@@ -417,7 +467,8 @@ def quantize_llama(
                 # stage 2: attention once, on the first norm's output as stage 1 saw it; its output is o_proj's input
                 hook = HessianHook(overlap_batches=True)
                 attn = []
-                run_until(block, sets[1][0], hook, keep=attn, entry=(block.self_attn, normed))
+                with _merged_linears(block.self_attn, [nm.rsplit(".", 1)[-1] for nm in sets[0]] if fused_elementwise else []):
+                    run_until(block, sets[1][0], hook, keep=attn, entry=(block.self_attn, normed))
                 del normed
                 quantise_set(gi, block, sets[1], hook)
                 # stage 3: h = x + o_proj(attn), z = norm2(h) feeds gate and up

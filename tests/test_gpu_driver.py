@@ -200,6 +200,33 @@ def test_one_pass_norm_and_gated_activation_keep_the_modules_roundings(amd, gpu,
         amd.ops.rmsnorm(x.cpu(), norm.weight.data, 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_merged_linears_return_the_separate_linears_bits(amd, gpu, dtype):
+    """q/k/v as one product with the concatenated weight (driver._merged_linears): each slice bit for bit the separate
+    Linear's output, one product per input, the modules restored afterwards; packed or biased layers are left alone."""
+    from gptq_v2_amd import driver
+    from gptq_v2_amd.quant import HipLinear
+    gen = torch.Generator(device=gpu).manual_seed(2)
+    parent = torch.nn.Module()
+    for name, rows in (("q_proj", 512), ("k_proj", 128), ("v_proj", 128)):
+        setattr(parent, name, HipLinear.from_weight((torch.randn(rows, 256, generator=gen, device=gpu) * 0.05).to(dtype)))
+    x = torch.randn(3, 70, 256, generator=gen, device=gpu).to(dtype)
+    want = [getattr(parent, n)(x) for n in ("q_proj", "k_proj", "v_proj")]
+    with driver._merged_linears(parent, ["q_proj", "k_proj", "v_proj"]) as merged:
+        assert merged._saved is not None and isinstance(parent.q_proj, driver._SliceOfMerged)
+        got = [getattr(parent, n)(x) for n in ("q_proj", "k_proj", "v_proj")]
+        assert got[0].data_ptr() == merged._shared["y"].data_ptr()            # one product, three views
+        x2 = x + 1
+        assert torch.equal(parent.k_proj(x2), merged._saved[1](x2)) and merged._shared["key"][0] == x2.data_ptr()   # a new input: a new product
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+        assert g.view(3, 70, -1, 64).transpose(1, 2).shape[1] == w.shape[-1] // 64   # the view the attention takes of it
+    assert type(parent.q_proj) is HipLinear
+    parent.k_proj = torch.nn.Linear(256, 128, bias=True).to(gpu).to(dtype)
+    with driver._merged_linears(parent, ["q_proj", "k_proj", "v_proj"]) as merged:
+        assert merged._saved is None and type(parent.q_proj) is HipLinear
+
+
 def test_staged_walk_with_one_pass_operators_agrees_with_the_modules(amd, gpu):
     """fused_elementwise on (the default) against off: the first set of block 0 sees a norm whose values may differ in
     the last bit, so levels are compared as a fraction and the final perplexities within fp16 steps."""
