@@ -78,6 +78,7 @@ SIGNATURES = {
     "gq_xtx_fold": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "gq_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p]),
     "gq_silu_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "gq_rope_inplace": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "gq_xtx_tail_workspace": (c_size_t, [c_int64]),
     "gq_xtx_accumulate_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "gq_xtx_fold_tail": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -1,12 +1,13 @@
-// The two bandwidth-bound operators of a Llama block that stand between the calibration path's GEMMs when the
-// block is replayed stage by stage: RMS normalisation and act(gate) * up.  As separate framework operators they
-// are seven and two passes over the activations; here each is one (read once, write once).
+// The bandwidth-bound operators of a Llama block that stand between the calibration path's GEMMs when the block is
+// replayed stage by stage: RMS normalisation, rotary position embedding and act(gate) * up.  As separate framework
+// operators they are seven, ten and two passes over the activations; here each is one (read once, write once).
 //
-// Both keep the roundings of the operator chains they replace, so that a replay through them sees the activations
+// All keep the roundings of the operator chains they replace, so that a replay through them sees the activations
 // the model's own modules would produce:
 //   norm:  x32 = float(x); v = mean(x32 * x32); y = x32 * rsqrt(v + eps); out = T(float(w) * float(T(y)))
+//   rope:  out = T(float(T(x * cos)) + float(T(rotate_half(x) * sin)))
 //   silu:  s = x32 / (1 + exp(-x32)); out = T(float(T(s)) * float(u))
-// (T = the 16-bit type of the model).  Only the order in which the squares are summed is this kernel's own.
+// (T = the 16-bit type of the model).  Only the order in which the norm's squares are summed is a kernel's own.
 #include "gq_common.h"
 
 namespace {
@@ -118,6 +119,49 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(T *__restrict__ out, cons
     }
 }
 
+// Rotary position embedding of `n_heads` adjacent heads per token, in place: for the two halves (lo, hi) of a head
+//   lo' = T(float(T(lo * cos_lo)) + float(T(-hi * sin_lo))),  hi' = T(float(T(hi * cos_hi)) + float(T(lo * sin_hi)))
+// -- the roundings of  x * cos + rotate_half(x) * sin  taken operator by operator in the 16-bit type.  Eight lanes
+// cover one head (8 elements of each half per lane and turn), a wave eight heads of one token.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T *__restrict__ x, int64_t row_stride, const T *__restrict__ cos_t,
+                                                   const T *__restrict__ sin_t, int64_t cs_batch_stride, int64_t seq,
+                                                   int64_t n_tokens, int n_heads, int head_dim)
+{
+    const int half = head_dim >> 1;
+    const int chunks = half >> 3;                        // 8-element chunks per half head
+    const int64_t per_token = (int64_t)n_heads * chunks;   // work items of one token
+    const int64_t total = n_tokens * per_token;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int64_t tok = it / per_token;
+        const int rem = (int)(it - tok * per_token);
+        const int head = rem / chunks, ch = rem - head * chunks;
+        const int64_t b = tok / seq, pos = tok - b * seq;
+        T *xp = x + tok * row_stride + (int64_t)head * head_dim + 8 * ch;
+        const T *cp = cos_t + b * cs_batch_stride + pos * head_dim + 8 * ch;
+        const T *sp = sin_t + b * cs_batch_stride + pos * head_dim + 8 * ch;
+        float lo[8], hi[8], cl[8], chh[8], sl[8], sh[8];
+        load8(xp, lo);
+        load8(xp + half, hi);
+        load8(cp, cl);
+        load8(cp + half, chh);
+        load8(sp, sl);
+        load8(sp + half, sh);
+        T olo[8], ohi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a0 = static_cast<float>(static_cast<T>(__fmul_rn(lo[i], cl[i])));
+            const float b0 = static_cast<float>(static_cast<T>(__fmul_rn(-hi[i], sl[i])));
+            const float a1 = static_cast<float>(static_cast<T>(__fmul_rn(hi[i], chh[i])));
+            const float b1 = static_cast<float>(static_cast<T>(__fmul_rn(lo[i], sh[i])));
+            olo[i] = static_cast<T>(__fadd_rn(a0, b0));
+            ohi[i] = static_cast<T>(__fadd_rn(a1, b1));
+        }
+        store8(xp, olo);
+        store8(xp + half, ohi);
+    }
+}
+
 template <typename T>
 int launch_rmsnorm(void *out, const void *x, const void *w, int64_t n_rows, int64_t hidden, float eps, hipStream_t s)
 {
@@ -163,6 +207,30 @@ extern "C" int gq_silu_mul(void *out, const void *gate, const void *up, int dtyp
     else
         hipLaunchKernelGGL(silu_mul_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (__bf16 *)out, (const __bf16 *)gate,
                            (const __bf16 *)up, n_chunks);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+extern "C" int gq_rope_inplace(void *x, int64_t row_stride, const void *cos_t, const void *sin_t, int64_t cs_batch_stride, int64_t n_batch,
+                               int64_t seq, int n_heads, int head_dim, int dtype, gq_stream_t stream)
+{
+    GQ_REQUIRE(x && cos_t && sin_t, "gq_rope_inplace: NULL pointer");
+    GQ_REQUIRE(dtype == GQ_F16 || dtype == GQ_BF16, "gq_rope_inplace: dtype %d is neither fp16 (0) nor bf16 (1)", dtype);
+    GQ_REQUIRE(n_batch >= 0 && seq >= 0 && n_heads > 0 && head_dim > 0 && head_dim % 16 == 0,
+               "gq_rope_inplace: head_dim must be a positive multiple of 16");
+    GQ_REQUIRE(row_stride >= (int64_t)n_heads * head_dim && row_stride % 8 == 0 && cs_batch_stride % 8 == 0 && cs_batch_stride >= 0,
+               "gq_rope_inplace: row stride %lld must cover the %d heads and be a multiple of 8", (long long)row_stride, n_heads);
+    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0, "gq_rope_inplace: pointers must be 16-byte aligned");
+    const int64_t n_tokens = n_batch * seq;
+    if (n_tokens == 0) return GQ_OK;
+    const int64_t total = n_tokens * n_heads * (head_dim / 16);
+    const unsigned grid = (unsigned)std::min<int64_t>(gq_cdiv(total, 256), 256 * 32);
+    if (dtype == GQ_F16)
+        hipLaunchKernelGGL(rope_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (_Float16 *)x, row_stride, (const _Float16 *)cos_t,
+                           (const _Float16 *)sin_t, cs_batch_stride, seq, n_tokens, n_heads, head_dim);
+    else
+        hipLaunchKernelGGL(rope_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (__bf16 *)x, row_stride, (const __bf16 *)cos_t,
+                           (const __bf16 *)sin_t, cs_batch_stride, seq, n_tokens, n_heads, head_dim);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

@@ -194,6 +194,48 @@ def _act_mul(act_fn, g: torch.Tensor, u: torch.Tensor, fused: bool) -> torch.Ten
     return act_fn(g) * u
 
 
+def _fast_attention_ok(attn: nn.Module, kwargs: dict, x: torch.Tensor) -> bool:
+    """Whether ``_llama_attention`` computes what ``attn`` would: the plain Llama attention (causal, no mask tensor, no
+    cache, SDPA), dense q/k/v of this library without bias, 16-bit activations on the GPU."""
+    try:
+        cfg = attn.config
+        pe = kwargs.get("position_embeddings")
+        mods = [attn.q_proj, attn.k_proj, attn.v_proj]
+        return (type(attn).__name__ == "LlamaAttention" and getattr(cfg, "_attn_implementation", None) == "sdpa"
+                and kwargs.get("attention_mask") is None and kwargs.get("past_key_values") is None
+                and isinstance(pe, (tuple, list)) and len(pe) == 2 and all(isinstance(t_, torch.Tensor) and t_.dim() == 3 for t_ in pe)
+                and pe[0].dtype == x.dtype and pe[0].shape[-1] == attn.head_dim and pe[0].shape[0] in (1, x.shape[0])
+                and bool(getattr(attn, "is_causal", False)) and not attn.training and getattr(attn, "sliding_window", None) is None
+                and x.is_cuda and x.dtype in _HALF and x.dim() == 3 and attn.head_dim % 16 == 0
+                and all(type(m) is HipLinear and m.bias is None and m.weight.device == x.device and m.weight.dtype == x.dtype for m in mods)
+                and attn.q_proj.out_features == cfg.num_attention_heads * attn.head_dim
+                and attn.k_proj.out_features == cfg.num_key_value_heads * attn.head_dim
+                and attn.v_proj.out_features == attn.k_proj.out_features)
+    except AttributeError:
+        return False
+
+
+def _llama_attention(attn: nn.Module, merged: nn.Module, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
+    """The input of o_proj for hidden states x (batch, seq, hidden), as LlamaAttention.forward computes it, in four
+    launches: q/k/v as one product with the concatenated weight (``merged``), the rotary embedding in place on its q
+    and k columns (ops.rope_inplace, the operators' roundings), the framework's fused attention on strided views of that
+    buffer, one copy of its output into (batch, seq, heads * head_dim).  The module's own path runs ten element-wise
+    operators over q and k for the rotary embedding and three products."""
+    b, s, _ = x.shape
+    d = attn.head_dim
+    hq, hkv = attn.config.num_attention_heads, attn.config.num_key_value_heads
+    cos, sin = kwargs["position_embeddings"]
+    qkv = merged(x)
+    ops.rope_inplace(qkv, cos.contiguous(), sin.contiguous(), hq + hkv, d)
+    q = qkv[..., :hq * d].view(b, s, hq, d).transpose(1, 2)
+    k = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
+    v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
+    extra = {"enable_gqa": True} if hkv != hq else {}
+    out = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, scale=attn.scaling,
+                                                           is_causal=s > 1, **extra)
+    return out.transpose(1, 2).reshape(b, s, hq * d).contiguous()
+
+
 class _SliceOfMerged(nn.Module):
     """Stands in for one of several Linears that read the same input: the first of them to be called runs ONE product
     with the concatenated weight, each returns its columns of it (a view)."""
@@ -467,8 +509,16 @@ def quantize_llama(
                 # stage 2: attention once, on the first norm's output as stage 1 saw it; its output is o_proj's input
                 hook = HessianHook(overlap_batches=True)
                 attn = []
-                with _merged_linears(block.self_attn, [nm.rsplit(".", 1)[-1] for nm in sets[0]] if fused_elementwise else []):
-                    run_until(block, sets[1][0], hook, keep=attn, entry=(block.self_attn, normed))
+                if fused_elementwise and _fast_attention_ok(block.self_attn, inp_kwargs, normed[0]):
+                    merged = HipLinear.from_weight(torch.cat([_submodule(block, nm).weight.data for nm in sets[0]], dim=0))
+                    for i in range(len(batches)):
+                        attn.append(_llama_attention(block.self_attn, merged, normed[i], inp_kwargs))
+                        normed[i] = None
+                        hook.add_batch(attn[i])
+                    del merged
+                else:
+                    with _merged_linears(block.self_attn, [nm.rsplit(".", 1)[-1] for nm in sets[0]] if fused_elementwise else []):
+                        run_until(block, sets[1][0], hook, keep=attn, entry=(block.self_attn, normed))
                 del normed
                 quantise_set(gi, block, sets[1], hook)
                 # stage 3: h = x + o_proj(attn), z = norm2(h) feeds gate and up

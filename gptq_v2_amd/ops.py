@@ -139,6 +139,26 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor, out: Optional[torch.Tensor] =
     return out
 
 
+def rope_inplace(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_heads: int, head_dim: int) -> torch.Tensor:
+    """Rotary embedding, in place, of the first ``n_heads * head_dim`` columns of x (batch, seq, columns) -- e.g. the q and k
+    parts of a merged q/k/v product -- with cos / sin (batch or 1, seq, head_dim) of x's type, rounded operator by
+    operator as ``x * cos + rotate_half(x) * sin`` is."""
+    _check(x, "x", None, 3)
+    _check(cos, "cos", x.dtype, 3)
+    _check(sin, "sin", x.dtype, 3)
+    code = _dtype_code(x)
+    b, s, cols = x.shape
+    if n_heads * head_dim > cols:
+        raise ValueError(f"{n_heads} heads of {head_dim} do not fit {cols} columns")
+    if cos.shape != sin.shape or cos.shape[1:] != (s, head_dim) or cos.shape[0] not in (1, b) or cos.device != x.device or sin.device != x.device:
+        raise ValueError(f"cos / sin are {tuple(cos.shape)} / {tuple(sin.shape)}, expected ({b} or 1, {s}, {head_dim}) on {x.device}")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().gq_rope_inplace(_p(x), cols, _p(cos), _p(sin), 0 if cos.shape[0] == 1 else s * head_dim, b, s, int(n_heads),
+                                         int(head_dim), code, _stream(x))
+    _lib.check(rc, "gq_rope_inplace")
+    return x
+
+
 def xtx_tail_workspace(hidden: int) -> int:
     """Bytes of the tail buffers ``xtx_accumulate_tail`` needs for this hidden size (0: the size has no tail split)."""
     return int(_lib.load().gq_xtx_tail_workspace(int(hidden)))

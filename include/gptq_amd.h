@@ -371,6 +371,16 @@ int gq_rmsnorm(void *out, const void *x, const void *weight, int dtype, int64_t 
                gq_stream_t stream);
 int gq_silu_mul(void *out, const void *gate, const void *up, int dtype, int64_t n, gq_stream_t stream);
 
+/* Rotary position embedding, in place, of n_heads adjacent heads of head_dim columns at the start of every row of
+ * x[n_batch * seq][row_stride] (e.g. the q and k columns of a merged q/k/v product), with cos / sin
+ * [n_batch or 1][seq][head_dim] (cs_batch_stride = seq * head_dim, or 0 when all sequences share the positions):
+ * x * cos + rotate_half(x) * sin with each product and the sum rounded to the 16-bit type, as the operators round.
+ * head_dim a multiple of 16, strides multiples of 8, pointers 16-byte aligned.
+ * ref: llama.py:172-190 replays the model's own attention module; this takes the place of its rotary embedding in
+ *      the stage-wise replay of gptq_v2_amd.driver.quantize_llama. */
+int gq_rope_inplace(void *x, int64_t row_stride, const void *cos_t, const void *sin_t, int64_t cs_batch_stride, int64_t n_batch,
+                    int64_t seq, int n_heads, int head_dim, int dtype, gq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

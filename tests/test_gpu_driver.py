@@ -227,6 +227,58 @@ def test_merged_linears_return_the_separate_linears_bits(amd, gpu, dtype):
         assert merged._saved is None and type(parent.q_proj) is HipLinear
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("heads,kv_heads,head_dim,seq", [(4, 2, 64, 96), (4, 4, 64, 33), (8, 2, 128, 160), (2, 2, 16, 1)])
+def test_attention_stage_equals_the_models_attention(amd, gpu, dtype, heads, kv_heads, head_dim, seq):
+    """driver._llama_attention (merged q/k/v, in-place rotary kernel, fused attention on strided views) against the
+    input LlamaAttention.forward hands to o_proj: bit for bit, with grouped and plain heads, per-sequence and shared
+    positions; ops.rope_inplace alone against apply_rotary_pos_emb."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.models.llama import modeling_llama as ml
+    from gptq_v2_amd import driver
+    from gptq_v2_amd.quant import HipLinear
+    hidden = heads * head_dim
+    cfg = transformers.LlamaConfig(vocab_size=64, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=1,
+                                   num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim,
+                                   max_position_embeddings=256, attn_implementation="sdpa")
+    torch.manual_seed(heads + seq)
+    attn = ml.LlamaAttention(cfg, layer_idx=0).to(gpu).to(dtype).eval()
+    for name in ("q_proj", "k_proj", "v_proj"):
+        setattr(attn, name, HipLinear.from_weight(getattr(attn, name).weight.data))
+    rot = ml.LlamaRotaryEmbedding(cfg).to(gpu)
+    batch = 3
+    x = torch.randn(batch, seq, hidden, device=gpu).to(dtype)
+    for per_sequence in (False, True):
+        pos = torch.arange(seq, device=gpu)[None]
+        if per_sequence:
+            pos = pos + torch.arange(batch, device=gpu)[:, None] * 7
+        cos, sin = rot(x, pos)
+        kwargs = {"position_embeddings": (cos, sin), "attention_mask": None, "past_key_values": None}
+        assert driver._fast_attention_ok(attn, kwargs, x)
+        seen = []
+        handle = attn.o_proj.register_forward_pre_hook(lambda _m, args: seen.append(args[0]))
+        with torch.no_grad():
+            attn(hidden_states=x, **kwargs)
+        handle.remove()
+        merged = HipLinear.from_weight(torch.cat([attn.q_proj.weight.data, attn.k_proj.weight.data, attn.v_proj.weight.data], dim=0))
+        with torch.no_grad():
+            got = driver._llama_attention(attn, merged, x, kwargs)
+        assert got.shape == seen[0].shape and got.is_contiguous()
+        assert torch.equal(got, seen[0]), (per_sequence, float((got.float() - seen[0].float()).abs().max()))
+        # the rotary kernel alone
+        q = torch.randn(batch, seq, (heads + kv_heads) * head_dim + 64, device=gpu).to(dtype)
+        qh = q[..., :heads * head_dim].view(batch, seq, heads, head_dim).transpose(1, 2)
+        kh = q[..., heads * head_dim:(heads + kv_heads) * head_dim].view(batch, seq, kv_heads, head_dim).transpose(1, 2)
+        wq, wk = ml.apply_rotary_pos_emb(qh, kh, cos, sin)
+        tail = q[..., (heads + kv_heads) * head_dim:].clone()
+        amd.ops.rope_inplace(q, cos, sin, heads + kv_heads, head_dim)
+        assert torch.equal(qh, wq) and torch.equal(kh, wk) and torch.equal(q[..., (heads + kv_heads) * head_dim:], tail)
+    # a mask tensor, a packed or biased projection: the module's own path
+    assert not driver._fast_attention_ok(attn, dict(kwargs, attention_mask=torch.ones(1, device=gpu)), x)
+    attn.k_proj = torch.nn.Linear(hidden, kv_heads * head_dim).to(gpu).to(dtype)
+    assert not driver._fast_attention_ok(attn, kwargs, x)
+
+
 def test_staged_walk_with_one_pass_operators_agrees_with_the_modules(amd, gpu):
     """fused_elementwise on (the default) against off: the first set of block 0 sees a norm whose values may differ in
     the last bit, so levels are compared as a fraction and the final perplexities within fp16 steps."""
