@@ -19,7 +19,7 @@ def timed(fn, reps=8):
     return s.elapsed_time(e) / reps
 
 
-for c in (11008, 5888, 9728, 13824, 14336):
+for c in [int(a) for a in sys.argv[1:]] or (11008, 5888, 9728, 13824, 14336):
     need = amd.ops.xtx_tail_workspace(c)
     if not need:
         print(json.dumps({"c": c, "tail": None})); continue
