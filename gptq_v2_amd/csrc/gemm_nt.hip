@@ -134,10 +134,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // scalar operands of the load).
 typedef __amdgpu_buffer_rsrc_t nt_rsrc_t;
 
-template <int DT>
+// EPI = 0: y = x w^T in the operands' 16-bit type.
+// EPI = 1: c32[m][n] -= sum_k x[m][k] w[n][k] on an fp32 matrix (leading dimension ldc), tiles on and below the diagonal
+//          only (tile list = the lower triangle, row by row; m_total == n_total): the symmetric rank-k update of the
+//          Cholesky factorisation with its fp32 operands split into bf16 pieces (see gq_syrk_sub_split below).
+template <int DT, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict__ y, const unsigned short *__restrict__ x,
                                                         const unsigned short *__restrict__ w, int64_t m_total, int64_t n_total,
-                                                        int64_t k_total, int tiles_n, int n_blocks, int band)
+                                                        int64_t k_total, int tiles_n, int n_blocks, int band,
+                                                        float *__restrict__ c32, int64_t ldc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -156,8 +161,17 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
         tile_end = start + q + (xcd < r ? 1 : 0);
     }
     if (tile0 >= tile_end) return;   // the whole workgroup leaves: no barrier is left waiting
-    const int tiles_m = n_blocks / tiles_n;
+    const int tiles_m = EPI == 1 ? tiles_n : n_blocks / tiles_n;
     auto tile_origin = [&](int bid, int64_t &m0, int64_t &n0) __attribute__((always_inline)) {
+        if constexpr (EPI == 1) {
+            // lower triangle, row by row: tile (ti, tj), tj <= ti, has index ti (ti + 1) / 2 + tj
+            int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+            while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+            while (ti * (ti + 1) / 2 > bid) --ti;
+            m0 = (int64_t)ti * NT;
+            n0 = (int64_t)(bid - ti * (ti + 1) / 2) * NT;
+            return;
+        }
         const int per_band = band * tiles_n;
         const int b = bid / per_band, within = bid - b * per_band;
         const int rows = min(band, tiles_m - b * band);
@@ -359,6 +373,25 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
     auto store_tile = [&](int t) __attribute__((always_inline)) {
         int64_t m0, n0;
         tile_origin(t, m0, n0);
+        if constexpr (EPI == 1) {
+            // (the extents are multiples of 4: whole 16-byte pieces)
+            float *cw = c32 + (m0 + wr * 128) * ldc + n0 + wc * 64;
+            const int rows_left = (int)min((int64_t)128, m_total - (m0 + wr * 128));
+            const int cols_left = (int)min((int64_t)64, n_total - (n0 + wc * 64));
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int row = b * 16 + l15;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int col = a * 16 + 4 * lg;
+                    if (row < rows_left && col < cols_left) {
+                        f32x4v *p = reinterpret_cast<f32x4v *>(cw + (int64_t)row * ldc + col);
+                        *p = *p - acc[a][b];
+                    }
+                }
+            }
+            return;
+        }
         unsigned short *yw = y + (m0 + wr * 128) * n_total + n0 + wc * 64;
         const int rows_left = (int)min((int64_t)128, m_total - (m0 + wr * 128));
         const int cols_left = (int)min((int64_t)64, n_total - (n0 + wc * 64));
@@ -452,10 +485,33 @@ extern "C" int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int6
     GQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int grid = std::min(n_blocks, grid_env > 0 ? grid_env : std::max(cus, 8));
     GQ_REQUIRE((int64_t)gq_cdiv(n_blocks, grid) * (k / NK) < (1ll << 30), "gq_gemm_nt: too many k-steps per workgroup");
-    auto kern = dtype == GQ_F16 ? gemm_nt_kernel<GQ_F16> : gemm_nt_kernel<GQ_BF16>;
+    auto kern = dtype == GQ_F16 ? gemm_nt_kernel<GQ_F16, 0> : gemm_nt_kernel<GQ_BF16, 0>;
     GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, N_LDS));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), N_LDS, (hipStream_t)stream, (unsigned short *)y,
-                       (const unsigned short *)x, (const unsigned short *)w, m, n, k, tiles_n, n_blocks, band);
+                       (const unsigned short *)x, (const unsigned short *)w, m, n, k, tiles_n, n_blocks, band, (float *)nullptr,
+                       (int64_t)0);
+    GQ_LAUNCH_CHECK();
+    return GQ_OK;
+}
+
+// c[n][n] (fp32, leading dimension ldc, lower tiles) -= x w^T for bf16 x, w [n][k] (rows k-contiguous, k a multiple
+// of 64, n of 4): the matrix-core product of gq_gemm_nt with an fp32 read-modify-write of c as its epilogue.
+// Library-internal (csrc/hessian.hip).
+int gq_gemm_nt_sub_lower_f32(float *c, int64_t ldc, const void *x, const void *w, int64_t n, int64_t k, hipStream_t stream)
+{
+    GQ_REQUIRE(c && x && w && n > 0 && k > 0 && k % NK == 0 && n % 4 == 0 && ldc % 4 == 0, "gq_gemm_nt_sub_lower_f32: bad arguments");
+    GQ_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)c) & 15) == 0, "gq_gemm_nt_sub_lower_f32: pointers must be 16-byte aligned");
+    GQ_REQUIRE(k < (1 << 21) && n < (1 << 22), "gq_gemm_nt_sub_lower_f32: at most 2^21 input and 2^22 output features");
+    const int tiles = (int)gq_cdiv(n, NT);
+    const int n_blocks = tiles * (tiles + 1) / 2;
+    int dev = 0, cus = 0;
+    GQ_HIP(hipGetDevice(&dev));
+    GQ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int grid = std::min(n_blocks, std::max(cus, 8));
+    auto kern = gemm_nt_kernel<GQ_BF16, 1>;
+    GQ_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, N_LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), N_LDS, stream, (unsigned short *)nullptr, (const unsigned short *)x,
+                       (const unsigned short *)w, n, n, k, tiles, n_blocks, 1, c, ldc);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
 }

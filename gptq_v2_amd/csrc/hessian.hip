@@ -13,6 +13,7 @@
 //                   (L22, L22^-1) = rec(D);   (L^-1)21 = -L22^-1 (L21 L11^-1)
 // whose products run on the fp32 MFMA GEMM (sgemm.hip) and whose 128x128 leaves are factored and
 // inverted inside one workgroup in LDS.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -648,6 +649,76 @@ int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *st
     return gq_sgemm(g, stream);
 }
 
+// ---- far updates on the 16-bit matrix core -------------------------------------------------------------
+// D -= L L^T for an fp32 panel L (rows x depth) as ONE bf16 product with fp32 accumulation: every entry is split into
+// three bf16 pieces, l = l1 + l2 + l3 (each the bf16 rounding of what the pieces before it leave: 24 significant bits in
+// all, the sum is l exactly up to its last bit), and the six products of pieces that reach 2^-18 of the largest are
+// summed -- l1 l1 + l1 l2 + l2 l1 + l1 l3 + l3 l1 + l2 l2; what is left out is below 2^-26 of a product.  The products
+// of bf16 pieces are exact in fp32, so the result carries fp32 rounding only in its additions, like the fp32 product it
+// replaces.  Written as x = [l1 | l1 | l2 | l1 | l3 | l2] and w = [l1 | l2 | l1 | l3 | l1 | l2] along k (6 x depth deep)
+// it is the k-contiguous "x w^T" of the replay GEMM, whose kernel runs it (gq_gemm_nt_sub_lower_f32) at six times the
+// flops and about twelve times the rate of the fp32 matrix instructions: twice as fast where the tiles fill the chip.
+__global__ __launch_bounds__(256) void split3_kernel(const float *__restrict__ src, int64_t ld, int64_t rows, int depth,
+                                                     unsigned short *__restrict__ xs, unsigned short *__restrict__ wsp)
+{
+    const int chunks = depth >> 3;                       // 8 entries per thread and turn
+    const int64_t total = rows * chunks;
+    const int64_t out_ld = (int64_t)6 * depth;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int64_t r = it / chunks;
+        const int k0 = (int)(it - r * chunks) * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + r * ld + k0);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(src + r * ld + k0 + 4);
+        unsigned short p[3][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = i < 4 ? v0[i] : v1[i - 4];
+            const __bf16 a1 = static_cast<__bf16>(a);
+            const float r1 = a - static_cast<float>(a1);          // exact
+            const __bf16 a2 = static_cast<__bf16>(r1);
+            const float r2 = r1 - static_cast<float>(a2);         // exact
+            const __bf16 a3 = static_cast<__bf16>(r2);
+            p[0][i] = __builtin_bit_cast(unsigned short, a1);
+            p[1][i] = __builtin_bit_cast(unsigned short, a2);
+            p[2][i] = __builtin_bit_cast(unsigned short, a3);
+        }
+        u32x4 q[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[t][i] = (unsigned)p[t][2 * i] | ((unsigned)p[t][2 * i + 1] << 16);
+        unsigned short *xo = xs + r * out_ld + k0, *wo = wsp + r * out_ld + k0;
+        constexpr int XP[6] = {0, 0, 1, 0, 2, 1}, WP[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            *reinterpret_cast<u32x4 *>(xo + (int64_t)b * depth) = q[XP[b]];
+            *reinterpret_cast<u32x4 *>(wo + (int64_t)b * depth) = q[WP[b]];
+        }
+    }
+}
+
+// Whether a far update of `rest` rows and `depth` columns goes through the split product: it runs in rounds of one
+// 256 x 256 tile per CU (about 89 us per round at depth 512 plus the split pass), the fp32 kernel at about 110 TFLOP/s.
+std::atomic<int> g_invert_split{-1};   // -1: not set yet (GQ_INVERT_SPLIT decides, else automatic)
+
+bool far_update_splits(int64_t rest, int64_t depth, size_t scratch_bytes)
+{
+    int mode = g_invert_split.load();   // 0 automatic, 1 never, 2 whenever the buffers fit
+    if (mode < 0) {
+        const char *e = getenv("GQ_INVERT_SPLIT");   // 0: never, anything else: wherever they fit
+        mode = !e ? 0 : atoi(e) == 0 ? 1 : 2;
+        int expect = -1;
+        g_invert_split.compare_exchange_strong(expect, mode);
+    }
+    if (mode == 1 || depth % 64 || rest % 4) return false;
+    if ((size_t)rest * 6 * depth * 2 * 2 > scratch_bytes) return false;
+    if (mode == 2) return true;
+    const int64_t t = gq_cdiv(rest, 256), tiles = t * (t + 1) / 2;
+    const double fp32_us = (double)rest * rest * depth / 110e6;
+    const double split_us = (double)gq_cdiv(tiles, 256) * (89.0 * depth / 512.0 + 8.0) + 25.0;
+    return split_us < 0.9 * fp32_us;
+}
+
 // The same (L, L^-1) with the triangular inverse taken off the factorisation's chain.
 //
 // Factorisation, right-looking over 128-column panels: leaf (L_jj^-1 of the diagonal block), panel
@@ -666,7 +737,8 @@ int cholinv_rec(float *w, float *linv, int64_t ld, int64_t o, int64_t n, int *st
 // count that is not a power of two leaves a chain of complete subtrees of decreasing size (the bits
 // of nb, left to right); they are joined right to left at the end, one unbatched pair of products
 // each.  X = L21 L11^-1 goes into w (its lower part is free once the factorisation is done).
-int cholinv_panels(float *w, float *linv, int64_t ld, int64_t n, int *status, hipStream_t stream)
+int cholinv_panels(float *w, float *linv, int64_t ld, int64_t n, int *status, hipStream_t stream, void *scratch = nullptr,
+                   size_t scratch_bytes = 0)
 {
     const int nb = (int)(n / NB);
     int rc;
@@ -701,9 +773,19 @@ int cholinv_panels(float *w, float *linv, int64_t ld, int64_t n, int *status, hi
         if (j + 1 == sp_end && sp_end < nb) {
             const int64_t s0 = (int64_t)((j / SP) * SP) * NB, e0 = (int64_t)sp_end * NB;
             float *pfar = linv + e0 * ld + s0;       // L[e0.., s0..e0)
-            g.a = pfar; g.b = pfar; g.c = w + e0 * ld + e0; g.m = (int)(n - e0); g.n = (int)(n - e0); g.k = (int)(e0 - s0);
-            g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_NONE; g.negate = 1; g.accumulate = 1; g.lower_only = 1;
-            if ((rc = gq_sgemm(g, stream))) return rc;
+            const int64_t rest2 = n - e0, depth = e0 - s0;
+            if (scratch && far_update_splits(rest2, depth, scratch_bytes)) {
+                unsigned short *xs = (unsigned short *)scratch, *wsp = xs + rest2 * 6 * depth;
+                const int64_t items = rest2 * (depth / 8);
+                hipLaunchKernelGGL(split3_kernel, dim3((unsigned)std::min<int64_t>(gq_cdiv(items, 256), 256 * 16)), dim3(256), 0, stream,
+                                   pfar, ld, rest2, (int)depth, xs, wsp);
+                GQ_LAUNCH_CHECK();
+                if ((rc = gq_gemm_nt_sub_lower_f32(w + e0 * ld + e0, ld, xs, wsp, rest2, 6 * depth, stream))) return rc;
+            } else {
+                g.a = pfar; g.b = pfar; g.c = w + e0 * ld + e0; g.m = (int)rest2; g.n = (int)rest2; g.k = (int)depth;
+                g.layout = GQ_A_MK | GQ_B_NK; g.trim = GQ_TRIM_NONE; g.negate = 1; g.accumulate = 1; g.lower_only = 1;
+                if ((rc = gq_sgemm(g, stream))) return rc;
+            }
         }
     }
     // node at block offset ob with a complete left part of n1 blocks and a complete right part of n2
@@ -777,6 +859,13 @@ size_t carve(InvertWorkspace &ws, char *base, int64_t c)
 int ew_blocks(int64_t total) { return (int)std::min<int64_t>(gq_cdiv(total, 256), 256 * 16); }
 
 }  // namespace
+
+extern "C" int gq_set_invert_split(int mode)
+{
+    GQ_REQUIRE(mode >= 0 && mode <= 2, "gq_set_invert_split: 0 (automatic), 1 (fp32 products) or 2 (split products wherever they fit), got %d", mode);
+    const int before = g_invert_split.exchange(mode);
+    return before < 0 ? 0 : before;
+}
 
 extern "C" size_t gq_hessian_invert_workspace(int64_t c)
 {
@@ -862,7 +951,7 @@ int invert_try(const InvertWorkspace &ws, float *hessian, const float *gathered,
     // the block diagonal (checked by running the GPU tests with linv filled with NaN)
     if (recursive) GQ_HIP(hipMemsetAsync(ws.linv, 0, (size_t)cp * cp * 4, stream));
     int rc = recursive ? cholinv_rec(ws.w, ws.linv, cp, 0, cp, ws.status, stream)
-                       : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream);
+                       : cholinv_panels(ws.w, ws.linv, cp, cp, ws.status, stream, ws.t, (size_t)c * c * 4);   // the gather target is free once damp_flip_kernel has read it
     if (rc) return rc;
     hipLaunchKernelGGL(flip_out_kernel, dim3(ew_blocks(c * c)), dim3(256), 0, stream, ws.linv, c, cp, hessian_inv, ws.status);
     GQ_LAUNCH_CHECK();

@@ -43,3 +43,8 @@ int gq_sgemm(const GqSgemmArgs &args, hipStream_t stream);
 // Experiments and tests: 1 = every launch takes the compiler-scheduled kernels (also GQ_SGEMM=plain in the
 // environment); results are bit-identical either way.
 void gq_sgemm_set_plain(int on);
+
+// c[n][n] (fp32, leading dimension ldc, tiles on and below the diagonal) -= x w^T for bf16 x, w [n][k] with k-contiguous
+// rows: the replay GEMM's kernel with an fp32 read-modify-write epilogue (csrc/gemm_nt.hip), used by the factorisation's
+// far updates on operands split into bf16 pieces (csrc/hessian.hip).
+int gq_gemm_nt_sub_lower_f32(float *c, int64_t ldc, const void *x, const void *w, int64_t n, int64_t k, hipStream_t stream);

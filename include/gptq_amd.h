@@ -97,6 +97,14 @@ int gq_xtx_fold_tail(float *hessian, float *tail_ws, int64_t hidden, gq_stream_t
 int gq_xtx_accumulate_f32(float *hessian, const float *x, int64_t n_tokens, int64_t hidden,
                           gq_stream_t stream);
 
+/* How the factorisation inside gq_hessian_invert applies its large symmetric updates D -= L L^T: 0 (the default) =
+ * chosen per update by size, 1 = always as fp32 matrix-core products, 2 = wherever the workspace allows as ONE bf16
+ * product of the operands split into three bf16 pieces each (six partial products, exact in fp32, summed in fp32:
+ * fp32-grade accuracy at about 1.4 times the rate on updates that fill the chip; C = 28672: 137 -> 126 ms per
+ * inversion).  Returns the previous setting, -1 on a bad argument.  A tuning knob of this library, no reference
+ * counterpart; the environment variable GQ_INVERT_SPLIT=0|1 sets the initial value (0: never, 1: wherever they fit). */
+int gq_set_invert_split(int mode);
+
 /* Bytes of workspace gq_hessian_invert needs for a C x C Hessian. */
 size_t gq_hessian_invert_workspace(int64_t c);
 

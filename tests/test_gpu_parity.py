@@ -764,3 +764,32 @@ def test_odd_widths_invert_and_quantise(amd, oracle, gpu, c):
     want = oracle.gptq_quant(w.cpu(), oh, gs, gb, use_kernel_semantics=True)
     for k in ("qweight", "scale", "qzero", "perm_inv"):
         assert torch.equal(res["quant_meta"][k], want["quant_meta"][k]), k
+
+
+@pytest.mark.parametrize("c", [4096, 3200])
+def test_invert_far_updates_as_split_bf16_products(amd, gpu, c):
+    """The factorisation's large updates D -= L L^T as one bf16 product of operands split into three bf16 pieces
+    (gq_set_invert_split(2): wherever the buffers fit) against fp32 products (1): U agrees to fp32 rounding noise, and
+    against an fp64 check U H U^T = I the split form is no worse than the fp32 one (its partial products are exact)."""
+    lib = amd._lib.load()
+    gen = torch.Generator(device=gpu).manual_seed(c)
+    x = (torch.randn(8192, c, generator=gen, device=gpu) * (1 + 3 * torch.rand(c, generator=gen, device=gpu))).half()
+    before = lib.gq_set_invert_split(1)
+    try:
+        res = {}
+        for mode in (1, 2):
+            lib.gq_set_invert_split(mode)
+            hook = amd.HessianHook()
+            hook.add_batch(x.view(4, 2048, c))
+            u = hook.invert(damp_ratio=1e-2, act_order=True)
+            hd, ud = hook.hessian.double(), u.double()
+            resid = float((ud @ hd @ ud.t() - torch.eye(c, device=gpu, dtype=torch.float64)).abs().max())
+            res[mode] = (u.clone(), hook.perm.clone(), resid)
+    finally:
+        lib.gq_set_invert_split(before)
+    assert lib.gq_set_invert_split(5) == -1
+    assert torch.equal(res[1][1], res[2][1])
+    diff = float((res[1][0] - res[2][0]).abs().max() / res[1][0].abs().max())
+    print(f"C={c}: |U_split - U_fp32| / max = {diff:.2e}; fp64 residual fp32 {res[1][2]:.2e}, split {res[2][2]:.2e}")
+    assert 0 < diff < 1e-4                        # the split path really ran, and agrees
+    assert res[2][2] <= 1.5 * res[1][2] + 1e-6
