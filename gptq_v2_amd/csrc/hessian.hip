@@ -237,6 +237,12 @@ __global__ void flip_out_kernel(const float *__restrict__ linv, int64_t c, int64
 // solves (one thread per row) so that nothing waits for it -- 71k: a solve is 120 broadcast LDS reads
 // and a 32-deep chain per row (1.9k cycles per panel against 0.7k for the MFMA form), and the inverse
 // read back from LDS on another wave took longer than the factorisation beside it.
+// Also measured and dropped: the inverse of a diagonal block woven into its factorisation instruction by instruction
+// (the updates that are not on the pivot's chain and the inverse's step j-1 dealt by hand into the issue slots between
+// the chain's dependent instructions; bit-identical U): 25.3k cycles for the woven loop against 16.7k + 5.5k for the two
+// loops one after the other -- a DPP fmac holds the issue port for about 8 cycles, more than the gap between two
+// dependent instructions of the chain, so every filler delays the chain.  (Of the 13k cycles booked on "inverse" above,
+// 7.5k are the LDS writes of L, its inverse and the transposed copy: 36 stores per lane and sub-panel.)
 constexpr int LLD = 132;                 // LDS row stride (floats): 16-byte aligned rows, 16 rows cover all banks
 constexpr int PB = 16;                   // panel width
 constexpr int SLD = 68;                  // stride of the 64x64 product scratch

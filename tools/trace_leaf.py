@@ -10,7 +10,7 @@ def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
            "-DGQ_LEAF_TRACE", *sys.argv[2:], "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-shared", "-o", SO] + \
-          [os.path.join(csrc, f) for f in ("gq_core.hip", "hessian.hip", "sgemm.hip")]
+          [os.path.join(csrc, f) for f in ("gq_core.hip", "hessian.hip", "sgemm.hip", "gemm_nt.hip")]
     subprocess.check_call(cmd)
 
 def run():
