@@ -246,9 +246,10 @@ class _SliceOfMerged(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         sh = self._shared
-        key = (x.data_ptr(), x._version, tuple(x.shape))
-        if sh.get("key") != key:
-            sh["key"], sh["y"] = key, sh["linear"](x)
+        # the input itself is kept (not its address: a freed tensor's memory may be handed to the next one) together
+        # with its version counter, so a product is reused only for the very tensor it was made from, unmodified
+        if sh.get("x") is not x or sh.get("version") != x._version:
+            sh["x"], sh["version"], sh["y"] = x, x._version, sh["linear"](x)
         return sh["y"][..., self._lo:self._hi]
 
 

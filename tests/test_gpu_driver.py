@@ -217,7 +217,9 @@ def test_merged_linears_return_the_separate_linears_bits(amd, gpu, dtype):
         got = [getattr(parent, n)(x) for n in ("q_proj", "k_proj", "v_proj")]
         assert got[0].data_ptr() == merged._shared["y"].data_ptr()            # one product, three views
         x2 = x + 1
-        assert torch.equal(parent.k_proj(x2), merged._saved[1](x2)) and merged._shared["key"][0] == x2.data_ptr()   # a new input: a new product
+        assert torch.equal(parent.k_proj(x2), merged._saved[1](x2)) and merged._shared["x"] is x2   # a new input: a new product
+        x2 += 1                                                                                    # the same tensor, modified in place: a new product
+        assert torch.equal(parent.v_proj(x2), merged._saved[2](x2))
     for g, w in zip(got, want):
         assert torch.equal(g, w)
         assert g.view(3, 70, -1, 64).transpose(1, 2).shape[1] == w.shape[-1] // 64   # the view the attention takes of it
