@@ -385,6 +385,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
                 for (int a = 0; a < 4; ++a) {
                     const int col = a * 16 + 4 * lg;
                     if (row < rows_left && col < cols_left) {
+                        // (fire-and-forget atomic adds of -acc, which wait for no load of c, were measured: 2.2 times as
+                        // long for the whole update -- one scalar atomic per element against one 16-byte access per four)
                         f32x4v *p = reinterpret_cast<f32x4v *>(cw + (int64_t)row * ldc + col);
                         *p = *p - acc[a][b];
                     }
