@@ -77,6 +77,7 @@ SIGNATURES = {
     "gq_xtx_split_hint": (c_int, [c_int64, c_int64, c_int]),
     "gq_xtx_accumulate_split": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gq_xtx_fold": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "gq_gemm_nt_sub_lower": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "gq_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p]),
     "gq_silu_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "gq_rope_inplace": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),

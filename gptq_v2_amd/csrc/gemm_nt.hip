@@ -164,12 +164,34 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
     const int tiles_m = EPI == 1 ? tiles_n : n_blocks / tiles_n;
     auto tile_origin = [&](int bid, int64_t &m0, int64_t &n0) __attribute__((always_inline)) {
         if constexpr (EPI == 1) {
-            // lower triangle, row by row: tile (ti, tj), tj <= ti, has index ti (ti + 1) / 2 + tj
-            int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
-            while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
-            while (ti * (ti + 1) / 2 > bid) --ti;
+            // Lower triangle in bands of four tile rows, column by column inside a band: the 32 tiles an XCD works on
+            // at a time are then about four rows by eight columns, twelve operand panels whose current k-slices its L2
+            // holds, where a row-by-row order has 33 (one x panel, 32 w panels) and every k-step of every tile goes
+            // past the L2.  Band r (rows 4r .. 4r + 3) holds 16 r + 10 tiles, the bands before it 8 r^2 + 2 r.
+            const int t_all = tiles_n;                 // tile rows = tile columns
+            const int full = t_all >> 2;               // complete bands
+            int r = (int)((sqrtf(1.0f + 8.0f * (float)bid) - 1.0f) * 0.125f);
+            while (8 * (r + 1) * (r + 1) + 2 * (r + 1) <= bid) ++r;
+            while (8 * r * r + 2 * r > bid) --r;
+            r = min(r, full);                          // the last, partial band takes what is left
+            const int base = 4 * r, nrows = min(4, t_all - base);
+            int within = bid - (8 * r * r + 2 * r);
+            int ti, tj;
+            if (within < nrows * base) {
+                tj = within / nrows;
+                ti = base + (within - tj * nrows);
+            } else {
+                within -= nrows * base;
+                int c = 0;
+                while (within >= nrows - c) {
+                    within -= nrows - c;
+                    ++c;
+                }
+                tj = base + c;
+                ti = base + c + within;
+            }
             m0 = (int64_t)ti * NT;
-            n0 = (int64_t)(bid - ti * (ti + 1) / 2) * NT;
+            n0 = (int64_t)tj * NT;
             return;
         }
         const int per_band = band * tiles_n;
@@ -374,22 +396,22 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(unsigned short *__restrict
         int64_t m0, n0;
         tile_origin(t, m0, n0);
         if constexpr (EPI == 1) {
-            // (the extents are multiples of 4: whole 16-byte pieces)
+            // The extents are multiples of 128 (the factorisation's panel width), so a wave's 128 x 64 part of the tile is
+            // inside the matrix as a whole or not at all: no per-element bounds, and the four 16-byte pieces a lane owns
+            // in one row are loaded together, then written together -- one round trip to memory per row block instead of
+            // one per piece (with a bounds test around every piece the compiler kept load, wait, store strictly in turn:
+            // 32 dependent round trips per tile, as long as the tile's 48 k-steps).
             float *cw = c32 + (m0 + wr * 128) * ldc + n0 + wc * 64;
-            const int rows_left = (int)min((int64_t)128, m_total - (m0 + wr * 128));
-            const int cols_left = (int)min((int64_t)64, n_total - (n0 + wc * 64));
+            const bool inside = m0 + wr * 128 < m_total && n0 + wc * 64 < n_total;   // wave-uniform
+            if (inside) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int row = b * 16 + l15;
+                for (int b = 0; b < 8; ++b) {
+                    float *pr = cw + (int64_t)(b * 16 + l15) * ldc + 4 * lg;
+                    f32x4v v[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int col = a * 16 + 4 * lg;
-                    if (row < rows_left && col < cols_left) {
-                        // (fire-and-forget atomic adds of -acc, which wait for no load of c, were measured: 2.2 times as
-                        // long for the whole update -- one scalar atomic per element against one 16-byte access per four)
-                        f32x4v *p = reinterpret_cast<f32x4v *>(cw + (int64_t)row * ldc + col);
-                        *p = *p - acc[a][b];
-                    }
+                    for (int a = 0; a < 4; ++a) v[a] = *reinterpret_cast<const f32x4v *>(pr + a * 16);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4v *>(pr + a * 16) = v[a] - acc[a][b];
                 }
             }
             return;
@@ -497,11 +519,12 @@ extern "C" int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int6
 }
 
 // c[n][n] (fp32, leading dimension ldc, lower tiles) -= x w^T for bf16 x, w [n][k] (rows k-contiguous, k a multiple
-// of 64, n of 4): the matrix-core product of gq_gemm_nt with an fp32 read-modify-write of c as its epilogue.
+// of 64, n of 128): the matrix-core product of gq_gemm_nt with an fp32 read-modify-write of c as its epilogue.
 // Library-internal (csrc/hessian.hip).
 int gq_gemm_nt_sub_lower_f32(float *c, int64_t ldc, const void *x, const void *w, int64_t n, int64_t k, hipStream_t stream)
 {
-    GQ_REQUIRE(c && x && w && n > 0 && k > 0 && k % NK == 0 && n % 4 == 0 && ldc % 4 == 0, "gq_gemm_nt_sub_lower_f32: bad arguments");
+    GQ_REQUIRE(c && x && w && n > 0 && k > 0 && k % NK == 0 && n % 128 == 0 && ldc % 4 == 0,
+               "gq_gemm_nt_sub_lower_f32: n must be a multiple of 128, k of 64, ldc of 4");
     GQ_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)c) & 15) == 0, "gq_gemm_nt_sub_lower_f32: pointers must be 16-byte aligned");
     GQ_REQUIRE(k < (1 << 21) && n < (1 << 22), "gq_gemm_nt_sub_lower_f32: at most 2^21 input and 2^22 output features");
     const int tiles = (int)gq_cdiv(n, NT);
@@ -516,4 +539,9 @@ int gq_gemm_nt_sub_lower_f32(float *c, int64_t ldc, const void *x, const void *w
                        (const unsigned short *)w, n, n, k, tiles, n_blocks, 1, c, ldc);
     GQ_LAUNCH_CHECK();
     return GQ_OK;
+}
+
+extern "C" int gq_gemm_nt_sub_lower(float *c, int64_t ldc, const void *x, const void *w, int64_t n, int64_t k, gq_stream_t stream)
+{
+    return gq_gemm_nt_sub_lower_f32(c, ldc, x, w, n, k, (hipStream_t)stream);
 }

@@ -716,7 +716,7 @@ bool far_update_splits(int64_t rest, int64_t depth, size_t scratch_bytes)
         int expect = -1;
         g_invert_split.compare_exchange_strong(expect, mode);
     }
-    if (mode == 1 || depth % 64 || rest % 4) return false;
+    if (mode == 1 || depth % 64 || rest % 128) return false;
     if ((size_t)rest * 6 * depth * 2 * 2 > scratch_bytes) return false;
     if (mode == 2) return true;
     const int64_t t = gq_cdiv(rest, 256), tiles = t * (t + 1) / 2;

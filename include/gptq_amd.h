@@ -368,6 +368,13 @@ int gq_set_quant_super(int on);
 int gq_gemm_nt(void *y, const void *x, const void *w, int64_t m, int64_t n, int64_t k, int dtype,
                gq_stream_t stream);
 
+/* c[n][n] (fp32, leading dimension ldc) -= x w^T on the tiles on and below the diagonal (256 x 256 tiles; the part of a
+ * diagonal tile above the diagonal is written too), for bf16 x, w [n][k] with k-contiguous rows: the replay GEMM's
+ * kernel with an fp32 read-modify-write epilogue.  n a multiple of 128, k of 64, ldc of 4; pointers 16-byte aligned.
+ * gq_hessian_invert uses it for the factorisation's large symmetric updates, with operands split into bf16 pieces
+ * (gq_set_invert_split); exported for measurement.  No reference counterpart. */
+int gq_gemm_nt_sub_lower(float *c, int64_t ldc, const void *x, const void *w, int64_t n, int64_t k, gq_stream_t stream);
+
 /* The two bandwidth-bound operators between the GEMMs of a Llama block's staged replay, one pass each, with the
  * roundings of the operator chains they replace (only the order of the sum of squares is the kernel's own):
  *   gq_rmsnorm:  out = T(float(weight) * float(T(float(x) * rsqrt(mean(float(x)^2) + eps))))   per row of `hidden`
