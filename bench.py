@@ -469,6 +469,22 @@ def end_to_end(torch, dev, bits, n_seq, batch):
             "reference_log": "123.45 s for the 32 blocks on an unnamed GPU (logs/log.txt:260), 3.78-3.97 s per block"}
 
 
+def device_peak(torch, dev):
+    """The dense 16-bit matrix peak from what the device reports: CUs x maximum clock x 4096 flops per clock and CU
+    (4 SIMDs x 1024: one v_mfma_f32_16x16x32_f16, 16384 flops, per 16 cycles and SIMD).  `peak` itself stays the
+    vendor's dense figure, 2.5 PFLOP/s."""
+    try:
+        import ctypes
+        from gptq_v2_amd import _lib
+        cus, khz = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().gq_device_info(ctypes.byref(cus), ctypes.byref(khz)), "gq_device_info")
+        return {"cus": cus.value, "max_clock_mhz": round(khz.value / 1e3, 1), "flops_per_clock_per_cu": 4096,
+                "tflops": round(cus.value * khz.value * 1e3 * 4096 / 1e12, 1)}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -605,7 +621,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(replay_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                          "traffic": pmc_bytes(args.traffic_json, "gemm_nt.hip") if args.replay == "dense" else None,
                          "avg_launch_ms": round(pr.total_ms() / max(pr.count(), 1), 4),
-                         "avg_launch_flops": round(flops[0] / max(pr.count(), 1), 1), "launches": pr.count()},
+                         "avg_launch_flops": round(flops[0] / max(pr.count(), 1), 1), "launches": pr.count(),
+                         "peak_from_device": device_peak(torch, dev)},
             "roofline_xtx": {"kernel": "xtx256_kernel (H += X^T X, C=%d, %d tokens per launch)" % (hidden, tokens_call),
                              "bound": "mfma", "achieved": round(xtx_tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(xtx_tflops / MFMA_F16_PEAK_TFLOPS, 4),

@@ -28,6 +28,7 @@ SIGNATURES = {
     "gq_xtx_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gq_xtx_accumulate_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "gq_set_invert_split": (c_int, [c_int]),
+    "gq_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gq_hessian_invert_workspace": (c_size_t, [c_int64]),
     "gq_hessian_invert": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_float, c_int,
                                   c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),

@@ -53,6 +53,11 @@ typedef void *gq_stream_t;
 const char *gq_last_error(void);
 int gq_version(void);
 
+/* Compute units and peak clock (kHz) of the current device, as the runtime reports them: what a caller needs to state
+ * a matrix-core peak next to a measurement (CUs x clock x 4096 flops per clock and CU for 16-bit operands).  No
+ * reference counterpart. */
+int gq_device_info(int *compute_units, int *max_clock_khz);
+
 /* H[c][c] (fp32) += X^T X for X[n_tokens][hidden] (fp16 or bf16), fp32 accumulation.
  * compute_lower_only != 0: only tiles on or below the diagonal are computed; unless
  * save_lower_only != 0 each strictly-lower tile is also written, transposed, to its mirror
